@@ -1,0 +1,16 @@
+"""MI355X-native bundle-adjustment hot path (HIP kernels behind a C ABI).
+
+Public surface mirrors the reference's solver interface:
+FullBundleAdjustmentSolver, PoseOnlyBundleAdjustmentSolver, Options, Summary.
+The numerical path lives in libba_hip.so (include/ba_hip.h); importing this
+package does not touch the GPU, creating a solver does.
+"""
+from .solver import (BaProblem, Camera, FullBundleAdjustmentSolver,  # noqa
+                     IterationStatus, OptimizationInfo, Options,
+                     PoseOnlyBundleAdjustmentSolver, SolverType, Summary)
+from . import scenes  # noqa
+
+__all__ = ["BaProblem", "Camera", "FullBundleAdjustmentSolver",
+           "IterationStatus", "OptimizationInfo", "Options",
+           "PoseOnlyBundleAdjustmentSolver", "SolverType", "Summary",
+           "scenes"]

@@ -1,0 +1,861 @@
+// ba_api.hip — implementation of the C ABI declared in include/ba_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ba_hip.h"
+#include "ba_device.h"
+#include "ba_plan.h"
+
+namespace ba {
+void launch_scalars_cost_only(const DevProblem &d, hipStream_t s);
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &m) {
+  g_err = m;
+  return -1;
+}
+
+#define HIP_TRY(expr)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess)                                                    \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+enum Stage { ST_BUILD = 0, ST_SCHUR, ST_SOLVE, ST_BACKSUB, ST_COST, ST_CTRL, ST_XCHG, ST_N = 8 };
+
+}  // namespace
+
+struct ba_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // host copies of the problem (scaled units)
+  int n_cam = 0, n_pose = 0, n_pt = 0;
+  int64_t n_obs = 0;
+  std::vector<double> cam_intr, cam_T, pose_T, pt_X, obs_uv;
+  std::vector<uint8_t> pose_fixed, pt_fixed;
+  std::vector<int32_t> obs_cam, obs_pose, obs_pt;
+  int rank = 0, world = 1;
+  bool finalized = false;
+  ba::Plan plan;
+  ba::DevProblem d;
+  std::vector<void *> allocs;
+  ba_allreduce_fn ar_fn = nullptr;
+  void *ar_user = nullptr;
+  int64_t xbuf_n[2] = {0, 0};
+  ba::DevCtrl hc;  // host mirror for the stage API
+  bool timing = false;
+  hipEvent_t ev[ST_N + 1];
+  bool ev_ok = false;
+  double stage_ms[ST_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool lm_begun = false;
+  // pose-only scratch (grown on demand, reused across calls)
+  int po_cap_n = 0, po_cap_it = 0;
+  float *po_X = nullptr, *po_uv = nullptr, *po_T = nullptr, *po_dbg = nullptr;
+  uint8_t *po_mask = nullptr;
+  ba::PoIter *po_iters = nullptr;
+  int *po_meta = nullptr;
+
+  template <class T>
+  int dalloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess)
+      return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+    allocs.push_back((void *)*p);
+    return 0;
+  }
+  template <class T>
+  int upload(T **p, const std::vector<T> &v) {
+    if (dalloc(p, v.size())) return -1;
+    if (!v.empty()) {
+      hipError_t e = hipMemcpy(*p, v.data(), v.size() * sizeof(T),
+                               hipMemcpyHostToDevice);
+      if (e != hipSuccess)
+        return fail(std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+    }
+    return 0;
+  }
+  void free_device() {
+    for (void *p : allocs) (void)hipFree(p);
+    allocs.clear();
+    finalized = false;
+  }
+};
+
+namespace {
+
+int use_device(ba_handle *h) {
+  HIP_TRY(hipSetDevice(h->device));
+  return 0;
+}
+
+// one stage boundary: optional event record
+inline void mark(ba_handle *h, int k) {
+  if (h->timing) (void)hipEventRecord(h->ev[k], h->stream);
+}
+
+int xchg(ba_handle *h, int which) {
+  if (!h->ar_fn) return 0;
+  void *ptr = which == 0 ? (void *)h->d.L : (void *)h->d.scal;
+  int rc = h->ar_fn(h->ar_user, which, ptr, h->xbuf_n[which], (void *)h->stream);
+  if (rc != 0) return fail("all-reduce hook returned an error");
+  return 0;
+}
+
+// Enqueue one LM iteration (reference :709-1007) without host sync.
+int enqueue_iteration(ba_handle *h) {
+  const ba::DevProblem &d = h->d;
+  hipStream_t s = h->stream;
+  mark(h, 0);
+  ba::launch_linearize(d, s);
+  mark(h, 1);
+  ba::launch_schur(d, s);
+  mark(h, 2);
+  if (xchg(h, 0)) return -1;
+  mark(h, 3);
+  ba::launch_dense_solve(d, s);
+  mark(h, 4);
+  ba::launch_backsub_update(d, s);
+  mark(h, 5);
+  ba::launch_cost(d, 1, s);
+  ba::launch_scalars(d, s);
+  mark(h, 6);
+  if (xchg(h, 1)) return -1;
+  mark(h, 7);
+  ba::launch_control(d, s);
+  mark(h, 8);
+  if (h->timing) {
+    HIP_TRY(hipStreamSynchronize(s));
+    static const int stage_of[8] = {ST_BUILD, ST_SCHUR, ST_XCHG,  ST_SOLVE,
+                                    ST_BACKSUB, ST_COST, ST_XCHG, ST_CTRL};
+    for (int k = 0; k < 8; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev[k], h->ev[k + 1]) == hipSuccess)
+        h->stage_ms[stage_of[k]] += ms;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int push_ctrl(ba_handle *h) {
+  HIP_TRY(hipMemcpyAsync(h->d.ctrl, &h->hc, sizeof(ba::DevCtrl),
+                         hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+int pull_ctrl(ba_handle *h) {
+  HIP_TRY(hipMemcpyAsync(&h->hc, h->d.ctrl, sizeof(ba::DevCtrl),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+template <class T>
+int download(std::vector<T> &out, const T *dev, size_t n, hipStream_t s) {
+  out.resize(n);
+  if (n == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(out.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ba_last_error(void) { return g_err.c_str(); }
+
+int ba_create(ba_handle **out, int device_id) {
+  if (!out) return fail("ba_create: null out pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail("ba_create: no HIP device available (the HIP path has no CPU "
+                "fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail("ba_create: bad device id");
+  ba_handle *h = new ba_handle();
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess ||
+      hipStreamCreate(&h->own_stream) != hipSuccess) {
+    delete h;
+    return fail("ba_create: cannot create stream");
+  }
+  h->stream = h->own_stream;
+  std::memset(&h->d, 0, sizeof(h->d));
+  std::memset(&h->hc, 0, sizeof(h->hc));
+  *out = h;
+  return 0;
+}
+
+void ba_destroy(ba_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->free_device();
+  if (h->ev_ok)
+    for (int k = 0; k <= ST_N; ++k) (void)hipEventDestroy(h->ev[k]);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int ba_set_stream(ba_handle *h, void *hip_stream) {
+  if (!h) return fail("null handle");
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return 0;
+}
+
+int ba_set_cameras(ba_handle *h, int n_cam, const double *intr4,
+                   const double *T_cj12) {
+  if (!h || n_cam <= 0 || !intr4 || !T_cj12) return fail("ba_set_cameras: bad argument");
+  if (h->finalized) return fail("ba_set_cameras: already finalized");
+  h->n_cam = n_cam;
+  h->cam_intr.assign(intr4, intr4 + 4 * (size_t)n_cam);
+  h->cam_T.assign(T_cj12, T_cj12 + 12 * (size_t)n_cam);
+  return 0;
+}
+
+int ba_set_poses(ba_handle *h, int n_pose, const double *T_jw12,
+                 const uint8_t *fixed) {
+  if (!h || n_pose <= 0 || !T_jw12) return fail("ba_set_poses: bad argument");
+  if (h->finalized) return fail("ba_set_poses: already finalized");
+  h->n_pose = n_pose;
+  h->pose_T.assign(T_jw12, T_jw12 + 12 * (size_t)n_pose);
+  if (fixed)
+    h->pose_fixed.assign(fixed, fixed + n_pose);
+  else
+    h->pose_fixed.assign(n_pose, 0);
+  return 0;
+}
+
+int ba_set_points(ba_handle *h, int n_pt, const double *X3,
+                  const uint8_t *fixed) {
+  if (!h || n_pt <= 0 || !X3) return fail("ba_set_points: bad argument");
+  if (h->finalized) return fail("ba_set_points: already finalized");
+  h->n_pt = n_pt;
+  h->pt_X.assign(X3, X3 + 3 * (size_t)n_pt);
+  if (fixed)
+    h->pt_fixed.assign(fixed, fixed + n_pt);
+  else
+    h->pt_fixed.assign(n_pt, 0);
+  return 0;
+}
+
+int ba_set_observations(ba_handle *h, int64_t n_obs, const int32_t *cam,
+                        const int32_t *pose, const int32_t *point,
+                        const double *uv2) {
+  if (!h || n_obs < 0 || (n_obs > 0 && (!cam || !pose || !point || !uv2)))
+    return fail("ba_set_observations: bad argument");
+  if (h->finalized) return fail("ba_set_observations: already finalized");
+  h->n_obs = n_obs;
+  h->obs_cam.assign(cam, cam + n_obs);
+  h->obs_pose.assign(pose, pose + n_obs);
+  h->obs_pt.assign(point, point + n_obs);
+  h->obs_uv.assign(uv2, uv2 + 2 * n_obs);
+  return 0;
+}
+
+int ba_set_shard(ba_handle *h, int rank, int world) {
+  if (!h || world < 1 || rank < 0 || rank >= world) return fail("ba_set_shard: bad argument");
+  if (h->finalized) return fail("ba_set_shard: already finalized");
+  h->rank = rank;
+  h->world = world;
+  return 0;
+}
+
+int ba_partition_points(int n_pose, const uint8_t *pose_fixed, int n_pt,
+                        const uint8_t *pt_fixed, int64_t n_obs,
+                        const int32_t *obs_pose, const int32_t *obs_pt,
+                        int world, int32_t *owner_out) {
+  if (n_pose <= 0 || n_pt <= 0 || world < 1 || !owner_out)
+    return fail("ba_partition_points: bad argument");
+  std::vector<uint8_t> pf(n_pose, 0), qf(n_pt, 0);
+  ba::PlanInput in;
+  in.n_cam = 1;
+  in.n_pose = n_pose;
+  in.pose_fixed = pose_fixed ? pose_fixed : pf.data();
+  in.n_pt = n_pt;
+  in.pt_fixed = pt_fixed ? pt_fixed : qf.data();
+  in.n_obs = n_obs;
+  in.obs_pose = obs_pose;
+  in.obs_pt = obs_pt;
+  in.world = world;
+  for (int64_t k = 0; k < n_obs; ++k)
+    if (obs_pose[k] < 0 || obs_pose[k] >= n_pose || obs_pt[k] < 0 || obs_pt[k] >= n_pt)
+      return fail("ba_partition_points: observation index out of range");
+  std::vector<int32_t> owner;
+  ba::partition_points(in, owner);
+  std::memcpy(owner_out, owner.data(), sizeof(int32_t) * (size_t)n_pt);
+  return 0;
+}
+
+int ba_finalize(ba_handle *h) {
+  if (!h) return fail("null handle");
+  if (h->finalized) return 0;  // idempotent (README of the reference calls it publicly)
+  if (h->n_cam <= 0 || h->n_pose <= 0 || h->n_pt <= 0)
+    return fail("ba_finalize: cameras, poses and points must be set first");
+  if (use_device(h)) return -1;
+  ba::PlanInput in;
+  in.n_cam = h->n_cam;
+  in.n_pose = h->n_pose;
+  in.pose_fixed = h->pose_fixed.data();
+  in.n_pt = h->n_pt;
+  in.pt_fixed = h->pt_fixed.data();
+  in.n_obs = h->n_obs;
+  in.obs_cam = h->obs_cam.data();
+  in.obs_pose = h->obs_pose.data();
+  in.obs_pt = h->obs_pt.data();
+  in.obs_uv = h->obs_uv.data();
+  in.rank = h->rank;
+  in.world = h->world;
+  std::string err = ba::build_plan(in, h->plan);
+  if (!err.empty()) return fail("ba_finalize: " + err);
+  const ba::Plan &pl = h->plan;
+  ba::DevProblem &d = h->d;
+  std::memset(&d, 0, sizeof(d));
+  d.n_cam = pl.n_cam; d.n_pose = pl.n_pose; d.N = pl.N; d.n_pt = pl.n_pt;
+  d.M = pl.M; d.M_global = pl.M_global; d.n_obs = pl.n_obs;
+  d.n_obs_opt = pl.n_obs_opt; d.n_obs_global = pl.n_obs_global; d.P = pl.P;
+  d.n_pobs = pl.n_pobs; d.T = pl.T; d.B = pl.B;
+  d.n_achunk = (int)pl.achunk_pose.size();
+  d.n_rchunk = (int)pl.rchunk_pose.size();
+  d.n_tchunk = (int)pl.tchunk_blk.size();
+
+  // parameters
+  std::vector<double> cams((size_t)pl.n_cam * 16);
+  for (int c = 0; c < pl.n_cam; ++c) {
+    std::memcpy(&cams[(size_t)c * 16], &h->cam_intr[(size_t)c * 4], 4 * sizeof(double));
+    std::memcpy(&cams[(size_t)c * 16 + 4], &h->cam_T[(size_t)c * 12], 12 * sizeof(double));
+  }
+  if (h->upload(&d.cams, cams)) return -1;
+  std::vector<double> poses((size_t)pl.n_pose * 12);
+  for (int p = 0; p < pl.n_pose; ++p)
+    std::memcpy(&poses[(size_t)p * 12], &h->pose_T[(size_t)pl.pose_user_of_int[p] * 12],
+                12 * sizeof(double));
+  if (h->upload(&d.poses[0], poses) || h->upload(&d.poses[1], poses)) return -1;
+  std::vector<double> pts((size_t)pl.n_pt * 3);
+  for (int q = 0; q < pl.n_pt; ++q)
+    std::memcpy(&pts[(size_t)q * 3], &h->pt_X[(size_t)pl.pt_user_of_int[q] * 3],
+                3 * sizeof(double));
+  if (h->upload(&d.pts[0], pts) || h->upload(&d.pts[1], pts)) return -1;
+
+  // structure
+  static_assert(sizeof(int4) == 16 && sizeof(double2) == 16, "layout");
+  if (h->dalloc(&d.obs_idx, (size_t)pl.n_obs)) return -1;
+  if (h->dalloc(&d.obs_uv, (size_t)pl.n_obs)) return -1;
+  if (pl.n_obs > 0) {
+    HIP_TRY(hipMemcpy(d.obs_idx, pl.obs_idx.data(), (size_t)pl.n_obs * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.obs_uv, pl.obs_uv.data(), (size_t)pl.n_obs * 16, hipMemcpyHostToDevice));
+  }
+  if (h->dalloc(&d.pobs_idx, (size_t)pl.n_pobs)) return -1;
+  if (h->dalloc(&d.pobs_uv, (size_t)pl.n_pobs)) return -1;
+  if (pl.n_pobs > 0) {
+    HIP_TRY(hipMemcpy(d.pobs_idx, pl.pobs_idx.data(), (size_t)pl.n_pobs * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.pobs_uv, pl.pobs_uv.data(), (size_t)pl.n_pobs * 16, hipMemcpyHostToDevice));
+  }
+  if (h->upload(&d.lm_obs_ptr, pl.lm_obs_ptr) || h->upload(&d.lm_pair_ptr, pl.lm_pair_ptr) ||
+      h->upload(&d.pair_pose, pl.pair_pose) || h->upload(&d.pair_lm, pl.pair_lm) ||
+      h->upload(&d.achunk_pose, pl.achunk_pose) || h->upload(&d.achunk_begin, pl.achunk_begin) ||
+      h->upload(&d.achunk_end, pl.achunk_end) || h->upload(&d.pose_achunk_ptr, pl.pose_achunk_ptr) ||
+      h->upload(&d.ppair, pl.ppair) || h->upload(&d.rchunk_pose, pl.rchunk_pose) ||
+      h->upload(&d.rchunk_begin, pl.rchunk_begin) || h->upload(&d.rchunk_end, pl.rchunk_end) ||
+      h->upload(&d.pose_rchunk_ptr, pl.pose_rchunk_ptr) || h->upload(&d.sblk_j, pl.sblk_j) ||
+      h->upload(&d.sblk_k, pl.sblk_k) || h->upload(&d.tri_p, pl.tri_p) ||
+      h->upload(&d.tri_q, pl.tri_q) || h->upload(&d.tchunk_blk, pl.tchunk_blk) ||
+      h->upload(&d.tchunk_begin, pl.tchunk_begin) || h->upload(&d.tchunk_end, pl.tchunk_end) ||
+      h->upload(&d.sblk_tchunk_ptr, pl.sblk_tchunk_ptr))
+    return -1;
+
+  // per-iteration storage
+  if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.b, (size_t)pl.M * 3) ||
+      h->dalloc(&d.Cinv, (size_t)pl.M * 6) || h->dalloc(&d.Cinvb, (size_t)pl.M * 3) ||
+      h->dalloc(&d.W, (size_t)pl.P * 18) || h->dalloc(&d.V, (size_t)pl.P * 18) ||
+      h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) || h->dalloc(&d.A, (size_t)pl.N * 36) ||
+      h->dalloc(&d.a, (size_t)pl.N * 6) || h->dalloc(&d.rpart, (size_t)d.n_rchunk * 6) ||
+      h->dalloc(&d.spart, (size_t)d.n_tchunk * 36) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
+      h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
+      h->dalloc(&d.lm_part, (size_t)ba::kLmGrid * 2) || h->dalloc(&d.pose_part, (size_t)2) ||
+      h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
+    return -1;
+  HIP_TRY(hipMemset(d.W, 0, std::max<size_t>(1, (size_t)pl.P * 18) * sizeof(double)));
+  HIP_TRY(hipMemset(d.V, 0, std::max<size_t>(1, (size_t)pl.P * 18) * sizeof(double)));
+  HIP_TRY(hipMemset(d.x, 0, ((size_t)pl.N * 6 + 64) * sizeof(double)));
+  HIP_TRY(hipMemset(d.y, 0, std::max<size_t>(1, (size_t)pl.M * 3) * sizeof(double)));
+  HIP_TRY(hipMemset(d.cost_part, 0, ba::kCostGrid * sizeof(double)));
+  HIP_TRY(hipMemset(d.lm_part, 0, ba::kLmGrid * 2 * sizeof(double)));
+  HIP_TRY(hipMemset(d.pose_part, 0, 2 * sizeof(double)));
+  HIP_TRY(hipMemset(d.scal, 0, 4 * sizeof(double)));
+  d.log_cap = 4096;
+  if (h->dalloc(&d.log, (size_t)d.log_cap)) return -1;
+
+  // dense reduced system
+  const int n6 = 6 * pl.N;
+  d.npad = std::max(ba::kDenseNb, ((n6 + ba::kDenseNb - 1) / ba::kDenseNb) * ba::kDenseNb);
+  d.ld = d.npad + ba::kDenseNb;
+  h->xbuf_n[0] = (int64_t)d.npad * d.ld;
+  h->xbuf_n[1] = 4;
+  if (h->dalloc(&d.L, (size_t)h->xbuf_n[0])) return -1;
+  const size_t ncb = (size_t)d.npad / ba::kDenseNb;
+  if (h->dalloc(&d.Ldiag, ncb * ba::kDenseNb * ba::kDenseNb + d.npad)) return -1;
+
+  std::memset(&h->hc, 0, sizeof(h->hc));
+  h->hc.lambda = 100.0;
+  h->hc.huber = 1.0;
+  h->hc.max_iter = 1;
+  HIP_TRY(hipMemcpy(d.ctrl, &h->hc, sizeof(ba::DevCtrl), hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  h->finalized = true;
+  return 0;
+}
+
+int ba_set_allreduce(ba_handle *h, ba_allreduce_fn fn, void *user) {
+  if (!h) return fail("null handle");
+  h->ar_fn = fn;
+  h->ar_user = user;
+  return 0;
+}
+
+int64_t ba_reduce_buffer_size(ba_handle *h, int which) {
+  if (!h || !h->finalized || which < 0 || which > 1) return -1;
+  return h->xbuf_n[which];
+}
+
+int ba_bind_reduce_buffer(ba_handle *h, int which, void *dev_ptr, int64_t n) {
+  if (!h || !h->finalized) return fail("ba_bind_reduce_buffer: not finalized");
+  if (which < 0 || which > 1 || !dev_ptr || n < h->xbuf_n[which])
+    return fail("ba_bind_reduce_buffer: bad argument");
+  if (which == 0)
+    h->d.L = (double *)dev_ptr;
+  else
+    h->d.scal = (double *)dev_ptr;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+int ba_lm_begin(ba_handle *h, const ba_options *opt) {
+  if (!h || !opt) return fail("ba_lm_begin: bad argument");
+  if (!h->finalized && ba_finalize(h)) return -1;
+  if (use_device(h)) return -1;
+  if (opt->max_num_iterations > h->d.log_cap) {
+    // grow the device-side iteration log
+    ba::DevIterRec *nl = nullptr;
+    if (h->dalloc(&nl, (size_t)opt->max_num_iterations)) return -1;
+    h->d.log = nl;
+    h->d.log_cap = opt->max_num_iterations;
+  }
+  if (pull_ctrl(h)) return -1;  // keep `cur`
+  ba::DevCtrl &c = h->hc;
+  c.lambda = (double)opt->initial_lambda;
+  c.huber = (double)opt->threshold_huber_loss;
+  c.thr_step = (double)opt->threshold_step_size;
+  c.thr_cost = (double)opt->threshold_cost_change;
+  c.dec_ratio = (double)opt->decrease_ratio_lambda;
+  c.inc_ratio = (double)opt->increase_ratio_lambda;
+  c.max_iter = opt->max_num_iterations;
+  c.iter = 0;
+  c.converged = 0;
+  c.done = (opt->max_num_iterations <= 0) ? 1 : 0;
+  c.prev_cost = 0.0;
+  const int done_after = c.done;
+  c.done = 0;
+  if (push_ctrl(h)) return -1;
+  // previous_cost = EvaluateCurrentCost()   (reference :707)
+  ba::launch_cost(h->d, 0, h->stream);
+  ba::launch_scalars_cost_only(h->d, h->stream);
+  if (xchg(h, 1)) return -1;
+  ba::launch_init_ctrl_cost(h->d, h->stream);
+  if (done_after) {
+    if (pull_ctrl(h)) return -1;
+    h->hc.done = 1;
+    if (push_ctrl(h)) return -1;
+  }
+  HIP_TRY(hipGetLastError());
+  h->lm_begun = true;
+  return 0;
+}
+
+int ba_lm_iterate(ba_handle *h, int n) {
+  if (!h || !h->lm_begun) return fail("ba_lm_iterate: call ba_lm_begin first");
+  if (use_device(h)) return -1;
+  for (int k = 0; k < n; ++k)
+    if (enqueue_iteration(h)) return -1;
+  return 0;
+}
+
+int ba_lm_sync(ba_handle *h, ba_iter_info *out, int cap, int *n_iter,
+               int *converged) {
+  if (!h || !h->lm_begun) return fail("ba_lm_sync: call ba_lm_begin first");
+  if (use_device(h)) return -1;
+  if (pull_ctrl(h)) return -1;
+  const int n = h->hc.iter;
+  if (n_iter) *n_iter = n;
+  if (converged) *converged = h->hc.converged;
+  if (out && cap > 0 && n > 0) {
+    static_assert(sizeof(ba::DevIterRec) == sizeof(ba_iter_info), "iter layout");
+    const int m = std::min(std::min(n, cap), h->d.log_cap);
+    HIP_TRY(hipMemcpy(out, h->d.log, (size_t)m * sizeof(ba_iter_info), hipMemcpyDeviceToHost));
+  }
+  return h->hc.done ? 1 : 0;  // 1 = loop finished
+}
+
+int ba_solve(ba_handle *h, const ba_options *opt, ba_iter_info *out, int cap,
+             int *n_iter, int *converged) {
+  if (ba_lm_begin(h, opt)) return -1;
+  int done = opt->max_num_iterations <= 0;
+  int issued = 0;
+  while (!done) {
+    const int batch = std::min(4, opt->max_num_iterations - issued);
+    if (batch <= 0) break;
+    if (ba_lm_iterate(h, batch)) return -1;
+    issued += batch;
+    int rc = ba_lm_sync(h, nullptr, 0, nullptr, nullptr);
+    if (rc < 0) return -1;
+    done = rc;
+  }
+  int rc = ba_lm_sync(h, out, cap, n_iter, converged);
+  return rc < 0 ? -1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// stage API
+int ba_stage_cost(ba_handle *h, double *cost) {
+  if (!h || !h->finalized || !cost) return fail("ba_stage_cost: bad argument");
+  if (use_device(h)) return -1;
+  if (pull_ctrl(h)) return -1;
+  h->hc.done = 0;
+  if (push_ctrl(h)) return -1;
+  ba::launch_cost(h->d, 0, h->stream);
+  ba::launch_scalars_cost_only(h->d, h->stream);
+  if (xchg(h, 1)) return -1;
+  HIP_TRY(hipMemcpyAsync(cost, h->d.scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ba_stage_linearize(ba_handle *h, double lambda, double huber) {
+  if (!h || !h->finalized) return fail("ba_stage_linearize: not finalized");
+  if (use_device(h)) return -1;
+  if (pull_ctrl(h)) return -1;
+  h->hc.done = 0;
+  h->hc.lambda = lambda;
+  h->hc.huber = huber;
+  if (push_ctrl(h)) return -1;
+  ba::launch_linearize(h->d, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int ba_stage_schur(ba_handle *h) {
+  if (!h || !h->finalized) return fail("ba_stage_schur: not finalized");
+  if (use_device(h)) return -1;
+  ba::launch_schur(h->d, h->stream);
+  if (xchg(h, 0)) return -1;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int ba_stage_solve_reduced(ba_handle *h) {
+  if (!h || !h->finalized) return fail("ba_stage_solve_reduced: not finalized");
+  if (use_device(h)) return -1;
+  ba::launch_dense_solve(h->d, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int ba_stage_backsub_update(ba_handle *h) {
+  if (!h || !h->finalized) return fail("ba_stage_backsub_update: not finalized");
+  if (use_device(h)) return -1;
+  ba::launch_backsub_update(h->d, h->stream);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int ba_stage_scalars(ba_handle *h, double *trial_cost, double *model_change,
+                     double *pose_step_sum, double *point_step_sum) {
+  if (!h || !h->finalized) return fail("ba_stage_scalars: not finalized");
+  if (use_device(h)) return -1;
+  ba::launch_cost(h->d, 1, h->stream);
+  ba::launch_scalars(h->d, h->stream);
+  if (xchg(h, 1)) return -1;
+  double sc[4], pp[2];
+  HIP_TRY(hipMemcpyAsync(sc, h->d.scal, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(pp, h->d.pose_part, sizeof(pp), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (trial_cost) *trial_cost = sc[0];
+  if (model_change) *model_change = -sc[1];
+  if (point_step_sum) *point_step_sum = sc[2];
+  if (pose_step_sum) *pose_step_sum = pp[1];
+  return 0;
+}
+
+int ba_stage_commit(ba_handle *h, int accept) {
+  if (!h || !h->finalized) return fail("ba_stage_commit: not finalized");
+  if (use_device(h)) return -1;
+  if (pull_ctrl(h)) return -1;
+  if (accept) h->hc.cur ^= 1;
+  if (push_ctrl(h)) return -1;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ba_enable_stage_timing(ba_handle *h, int on) {
+  if (!h) return fail("null handle");
+  if (use_device(h)) return -1;
+  if (on && !h->ev_ok) {
+    for (int k = 0; k <= ST_N; ++k) HIP_TRY(hipEventCreate(&h->ev[k]));
+    h->ev_ok = true;
+  }
+  h->timing = on != 0;
+  return 0;
+}
+
+int ba_get_stage_ms(ba_handle *h, double out8[8], int reset) {
+  if (!h || !out8) return fail("ba_get_stage_ms: bad argument");
+  for (int k = 0; k < 8; ++k) out8[k] = h->stage_ms[k];
+  if (reset)
+    for (int k = 0; k < 8; ++k) h->stage_ms[k] = 0.0;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// readers
+int ba_num_opt_poses(ba_handle *h) { return (h && h->finalized) ? h->plan.N : -1; }
+int ba_num_opt_points(ba_handle *h) { return (h && h->finalized) ? h->plan.M : -1; }
+int64_t ba_num_pairs(ba_handle *h) { return (h && h->finalized) ? h->plan.P : -1; }
+int64_t ba_num_schur_blocks(ba_handle *h) { return (h && h->finalized) ? h->plan.B : -1; }
+int64_t ba_num_schur_triples(ba_handle *h) { return (h && h->finalized) ? h->plan.T : -1; }
+
+int ba_get_poses(ba_handle *h, double *T_jw12) {
+  if (!h || !h->finalized || !T_jw12) return fail("ba_get_poses: bad argument");
+  if (use_device(h) || pull_ctrl(h)) return -1;
+  std::vector<double> buf;
+  if (download(buf, h->d.poses[h->hc.cur], (size_t)h->plan.n_pose * 12, h->stream)) return -1;
+  for (int p = 0; p < h->plan.n_pose; ++p)
+    std::memcpy(T_jw12 + (size_t)h->plan.pose_user_of_int[p] * 12, &buf[(size_t)p * 12],
+                12 * sizeof(double));
+  return 0;
+}
+
+int ba_get_points(ba_handle *h, double *X3, uint8_t *owned_mask) {
+  if (!h || !h->finalized || !X3) return fail("ba_get_points: bad argument");
+  if (use_device(h) || pull_ctrl(h)) return -1;
+  std::vector<double> buf;
+  if (download(buf, h->d.pts[h->hc.cur], (size_t)h->plan.n_pt * 3, h->stream)) return -1;
+  if (owned_mask) std::memset(owned_mask, 0, (size_t)h->plan.n_pt_global);
+  for (int q = 0; q < h->plan.n_pt; ++q) {
+    const int u = h->plan.pt_user_of_int[q];
+    std::memcpy(X3 + (size_t)u * 3, &buf[(size_t)q * 3], 3 * sizeof(double));
+    if (owned_mask) owned_mask[u] = 1;
+  }
+  return 0;
+}
+
+int ba_get_A(ba_handle *h, double *A36, double *a6) {
+  if (!h || !h->finalized) return fail("ba_get_A: not finalized");
+  if (use_device(h)) return -1;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (A36) HIP_TRY(hipMemcpy(A36, h->d.A, (size_t)h->plan.N * 36 * sizeof(double), hipMemcpyDeviceToHost));
+  if (a6) HIP_TRY(hipMemcpy(a6, h->d.a, (size_t)h->plan.N * 6 * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static void expand_sym3(const double *s6, double *f9) {
+  f9[0] = s6[0]; f9[1] = s6[1]; f9[2] = s6[2];
+  f9[3] = s6[1]; f9[4] = s6[3]; f9[5] = s6[4];
+  f9[6] = s6[2]; f9[7] = s6[4]; f9[8] = s6[5];
+}
+
+static int get_sym_vec(ba_handle *h, const double *dS6, const double *dV3,
+                       double *out9, double *out3) {
+  const ba::Plan &pl = h->plan;
+  std::vector<double> s6, v3;
+  if (download(s6, dS6, (size_t)pl.M * 6, h->stream)) return -1;
+  if (download(v3, dV3, (size_t)pl.M * 3, h->stream)) return -1;
+  for (int i = 0; i < pl.M; ++i) {
+    const int g = pl.iopt_of_user[pl.pt_user_of_int[i]];
+    if (out9) expand_sym3(&s6[(size_t)i * 6], out9 + (size_t)g * 9);
+    if (out3) std::memcpy(out3 + (size_t)g * 3, &v3[(size_t)i * 3], 3 * sizeof(double));
+  }
+  return 0;
+}
+
+int ba_get_C(ba_handle *h, double *C9, double *b3) {
+  if (!h || !h->finalized) return fail("ba_get_C: not finalized");
+  if (use_device(h)) return -1;
+  return get_sym_vec(h, h->d.Cd, h->d.b, C9, b3);
+}
+
+int ba_get_Cinv(ba_handle *h, double *Cinv9, double *Cinvb3) {
+  if (!h || !h->finalized) return fail("ba_get_Cinv: not finalized");
+  if (use_device(h)) return -1;
+  return get_sym_vec(h, h->d.Cinv, h->d.Cinvb, Cinv9, Cinvb3);
+}
+
+int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18) {
+  if (!h || !h->finalized) return fail("ba_get_pairs: not finalized");
+  if (use_device(h)) return -1;
+  const ba::Plan &pl = h->plan;
+  for (int64_t p = 0; p < pl.P; ++p) {
+    if (pair_i) pair_i[p] = pl.iopt_of_user[pl.pt_user_of_int[pl.pair_lm[p]]];
+    if (pair_j) pair_j[p] = pl.pair_pose[p];
+  }
+  if (W18) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (pl.P > 0)
+      HIP_TRY(hipMemcpy(W18, h->d.W, (size_t)pl.P * 18 * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int ba_get_S(ba_handle *h, double *S, double *rhs) {
+  if (!h || !h->finalized) return fail("ba_get_S: not finalized");
+  if (use_device(h)) return -1;
+  const ba::DevProblem &d = h->d;
+  const int n6 = 6 * h->plan.N;
+  std::vector<double> L;
+  if (download(L, d.L, (size_t)d.npad * d.ld, h->stream)) return -1;
+  for (int c = 0; c < n6; ++c) {
+    for (int r = c; r < n6; ++r) {
+      const double v = L[(size_t)c * d.ld + r];
+      if (S) {
+        S[(size_t)r * n6 + c] = v;
+        S[(size_t)c * n6 + r] = v;
+      }
+    }
+    if (rhs) rhs[c] = L[(size_t)c * d.ld + d.npad];
+  }
+  return 0;
+}
+
+int ba_get_xy(ba_handle *h, double *x6, double *y3) {
+  if (!h || !h->finalized) return fail("ba_get_xy: not finalized");
+  if (use_device(h)) return -1;
+  const ba::Plan &pl = h->plan;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (x6 && pl.N > 0)
+    HIP_TRY(hipMemcpy(x6, h->d.x, (size_t)pl.N * 6 * sizeof(double), hipMemcpyDeviceToHost));
+  if (y3) {
+    std::vector<double> y;
+    if (download(y, h->d.y, (size_t)pl.M * 3, h->stream)) return -1;
+    for (int i = 0; i < pl.M; ++i) {
+      const int g = pl.iopt_of_user[pl.pt_user_of_int[i]];
+      std::memcpy(y3 + (size_t)g * 3, &y[(size_t)i * 3], 3 * sizeof(double));
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
+                       double *x, double *ms) {
+  if (!h || n <= 0 || !A || !b || !x) return fail("ba_dense_spd_solve: bad argument");
+  if (use_device(h)) return -1;
+  const int nb = ba::kDenseNb;
+  const int npad = ((n + nb - 1) / nb) * nb;
+  const int ld = npad + nb;
+  std::vector<double> L((size_t)npad * ld, 0.0);
+  for (int c = 0; c < npad; ++c) {
+    if (c < n) {
+      for (int r = c; r < n; ++r) L[(size_t)c * ld + r] = A[(size_t)r * n + c];
+      L[(size_t)c * ld + npad] = b[c];
+    } else {
+      L[(size_t)c * ld + c] = 1.0;
+    }
+  }
+  double *dL = nullptr, *dD = nullptr, *dx = nullptr;
+  const size_t ncb = (size_t)npad / nb;
+  HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&dD, (ncb * nb * nb + npad) * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&dx, (size_t)npad * sizeof(double)));
+  HIP_TRY(hipMemcpy(dL, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, h->stream));
+  ba::dense_factor_solve(dL, npad, ld, dD, dx, n, nullptr, h->stream);
+  HIP_TRY(hipEventRecord(e1, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float t = 0.f;
+  (void)hipEventElapsedTime(&t, e0, e1);
+  if (ms) *ms = t;
+  HIP_TRY(hipMemcpy(x, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(dL);
+  (void)hipFree(dD);
+  (void)hipFree(dx);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+
+int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
+                       float fx, float fy, float cx, float cy, float *T12,
+                       uint8_t *mask, const ba_options *opt, ba_po_iter *iters,
+                       int cap, int *n_iter, int *converged,
+                       float *debug_T12) {
+  if (!h || !X3 || !uv2 || n <= 0 || !T12 || !mask || !opt)
+    return fail("ba_pose_only_mono6: bad argument");
+  if (use_device(h)) return -1;
+  static_assert(sizeof(ba::PoIter) == sizeof(ba_po_iter), "po iter layout");
+  const int max_it = opt->max_num_iterations;
+  const int icap = std::max(1, std::max(cap, max_it));
+  if (n > h->po_cap_n) {
+    if (h->dalloc(&h->po_X, (size_t)n * 3) || h->dalloc(&h->po_uv, (size_t)n * 2) ||
+        h->dalloc(&h->po_mask, (size_t)n))
+      return -1;
+    h->po_cap_n = n;
+  }
+  if (icap > h->po_cap_it || !h->po_T) {
+    if (h->dalloc(&h->po_iters, (size_t)icap) || h->dalloc(&h->po_dbg, (size_t)icap * 12))
+      return -1;
+    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4)))
+      return -1;
+    h->po_cap_it = icap;
+  }
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->po_X, X3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_uv, uv2, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_mask, mask, (size_t)n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_T, T12, 12 * sizeof(float), hipMemcpyHostToDevice, s));
+  if (ba::pose_only_mono6_device(h->po_X, h->po_uv, n, fx, fy, cx, cy, h->po_T, h->po_mask,
+                                 opt->threshold_huber_loss, opt->threshold_step_size,
+                                 opt->threshold_cost_change, opt->threshold_outlier_rejection,
+                                 max_it, h->po_iters, icap, h->po_meta,
+                                 debug_T12 ? h->po_dbg : nullptr, s))
+    return fail("pose-only kernel launch failed");
+  int meta[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(meta, h->po_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(T12, h->po_T, 12 * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(mask, h->po_mask, (size_t)n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
+  const int rows = std::min(meta[2], cap);
+  if (iters && rows > 0)
+    HIP_TRY(hipMemcpy(iters, h->po_iters, (size_t)rows * sizeof(ba_po_iter), hipMemcpyDeviceToHost));
+  if (debug_T12 && meta[0] > 0)
+    HIP_TRY(hipMemcpy(debug_T12, h->po_dbg, (size_t)std::min(meta[0], cap) * 12 * sizeof(float),
+                      hipMemcpyDeviceToHost));
+  if (n_iter) *n_iter = meta[0];
+  if (converged) *converged = meta[1];
+  return meta[3] ? 0 : 1;  // 1 = NaN pose, input left unchanged (reference :159-167)
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// ba_device.h — device-side structures and launcher prototypes shared by the
+// HIP translation units (internal; the public boundary is include/ba_hip.h).
+#ifndef BA_DEVICE_H_
+#define BA_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ba {
+
+// LM controller state, resident in device memory so that a whole batch of
+// iterations can be enqueued without host round trips.  Mirrors the locals of
+// reference core/full_bundle_adjustment_solver.cpp:705-1008.
+struct DevCtrl {
+  double lambda;
+  double prev_cost;
+  double huber;
+  double thr_step;
+  double thr_cost;
+  double dec_ratio;
+  double inc_ratio;
+  unsigned long long t_last;  // wall_clock64 stamp of the previous iteration
+  int cur;        // which parameter buffer holds the accepted parameters
+  int done;       // set once converged / max_iter reached: kernels no-op
+  int iter;       // iterations completed
+  int converged;
+  int max_iter;
+  int pad_[3];
+};
+
+struct DevIterRec {  // layout-identical to ba_iter_info
+  double cost, cost_change, average_reprojection_error, abs_gradient, abs_step,
+      damping_term, iter_time_ms;
+  int iteration_status, pad_;
+  double rho, model_change, trial_cost;
+};
+
+// All device pointers of one problem shard.
+struct DevProblem {
+  // sizes
+  int n_cam, n_pose, N, n_pt, M, M_global;
+  int64_t n_obs, n_obs_opt, n_obs_global, P, n_pobs, T, B;
+  int n_achunk, n_rchunk, n_tchunk;
+  // parameters: two buffers each (accepted / trial), selected by ctrl->cur
+  double *cams;      // n_cam*16: fx fy cx cy R9 t3
+  double *poses[2];  // n_pose*12
+  double *pts[2];    // n_pt*3
+  // landmark-major observations
+  int4 *obs_idx;
+  double2 *obs_uv;
+  int64_t *lm_obs_ptr;
+  int64_t *lm_pair_ptr;
+  int32_t *pair_pose;
+  int32_t *pair_lm;
+  // pose-major observations
+  int4 *pobs_idx;
+  double2 *pobs_uv;
+  int32_t *achunk_pose;
+  int64_t *achunk_begin, *achunk_end;
+  int32_t *pose_achunk_ptr;
+  // pose-major pairs
+  int64_t *ppair;
+  int32_t *rchunk_pose;
+  int64_t *rchunk_begin, *rchunk_end;
+  int32_t *pose_rchunk_ptr;
+  // Schur structure
+  int32_t *sblk_j, *sblk_k;
+  int64_t *tri_p, *tri_q;
+  int32_t *tchunk_blk;
+  int64_t *tchunk_begin, *tchunk_end;
+  int32_t *sblk_tchunk_ptr;
+  // per-iteration blocks
+  double *Cd;      // M*6   damped C_i upper (00 01 02 11 12 22)
+  double *b;       // M*3
+  double *Cinv;    // M*6   symmetric inverse upper
+  double *Cinvb;   // M*3
+  double *W;       // P*18  B_ji 6x3 row-major
+  double *V;       // P*18  B_ji Cinv_i
+  double *Apart;   // n_achunk*27
+  double *A;       // N*36  damped, full
+  double *a;       // N*6
+  double *rpart;   // n_rchunk*6
+  double *spart;   // n_tchunk*36
+  double *x;       // 6N
+  double *y;       // M*3
+  // scalar reductions
+  double *cost_part;   // kCostGrid
+  double *lm_part;     // kLmGrid*2 : model (landmark side), sum |y|
+  double *pose_part;   // 2 : model (pose side), sum |x|
+  double *scal;        // exchange buffer 1: [0] cost [1] model est [2] sum|y|
+  // controller
+  DevCtrl *ctrl;
+  DevIterRec *log;
+  int log_cap;
+  // dense reduced system (exchange buffer 0): column-major lower, ld rows
+  double *L;
+  int npad, ld;
+  double *Ldiag;   // (npad/64) * 64*64 diagonal factors (column-major)
+};
+
+constexpr int kCostGrid = 1024;
+constexpr int kLmGrid = 1024;
+constexpr int kDenseNb = 64;
+
+// ---- launchers (ba_kernels.hip) ----
+// sel: 0 = accepted parameters, 1 = trial parameters
+void launch_cost(const DevProblem &d, int sel, hipStream_t s);
+void launch_linearize(const DevProblem &d, hipStream_t s);
+void launch_schur(const DevProblem &d, hipStream_t s);
+void launch_backsub_update(const DevProblem &d, hipStream_t s);
+void launch_scalars(const DevProblem &d, hipStream_t s);
+void launch_control(const DevProblem &d, hipStream_t s);
+void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s);
+
+// ---- dense solver (ba_dense.hip) ----
+// Factor the npad x npad lower matrix in d.L (with the rhs carried as row
+// `npad`) and write x (first 6N entries).
+void launch_dense_solve(const DevProblem &d, hipStream_t s);
+// stand-alone helpers for ba_dense_spd_solve
+void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
+                        int n_x, const int *done_flag, hipStream_t s);
+void launch_dense_init(double *L, int npad, int ld, int n_valid,
+                       const int *done_flag, hipStream_t s);
+
+// ---- pose-only (ba_pose_only.hip) ----
+struct PoIter {
+  float cost, cost_change, abs_step;
+};
+int pose_only_mono6_device(const float *dX3, const float *duv2, int n, float fx,
+                           float fy, float cx, float cy, float *dT12_inout,
+                           uint8_t *dmask, float thr_huber, float thr_step,
+                           float thr_cost, float thr_out, int max_it,
+                           PoIter *d_iters, int cap, int *d_meta,
+                           float *d_debug, hipStream_t s);
+
+}  // namespace ba
+#endif

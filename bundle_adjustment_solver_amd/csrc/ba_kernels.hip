@@ -1,0 +1,768 @@
+// ba_kernels.hip — gfx950 kernels of the full-BA LM iteration.
+//
+// Stage map (reference core/full_bundle_adjustment_solver.cpp):
+//   k_cost                 :381-433   sum of residual norms
+//   k_lin_landmarks        :716-831 (landmark side: C_i, b_i, W_ji)
+//                          + :846-856 (damp, 3x3 LDLT pseudo-inverse, Cinv b)
+//   k_lin_poses/_finalize  :716-810 (pose side: A_j, a_j) + :833-844 (damp)
+//   k_pair_bcinv           :862      V_ji = W_ji Cinv_i
+//   k_rhs_partial          :864,:887 rhs_j = a_j - sum_i V_ji b_i
+//   k_schur_partial/_final :866-885  S_jk = d_jk A_j - sum_i V_ji W_ki^T
+//   k_backsub_update       :910-917 (y_i), :495-499 (X += y), :442-452 model
+//   k_pose_update          :487-494 (exp(x) T), :437-441 model, :962 |x|
+//   k_scalars / k_control  :928-1007 trust region, convergence, log
+//
+// All reductions use fixed grids and fixed summation trees: results are
+// bitwise reproducible run to run (no floating-point atomics anywhere).
+#include "ba_device.h"
+#include "ba_plan.h"
+
+namespace ba {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in thread 0.  `sm` holds >= 4.
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wv] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) r += sm[w];
+  }
+  return r;
+}
+
+// Projection of one observation; reference :743-760 / :413-425.
+struct ObsGeom {
+  double Xij[3];
+  double Xc[3];
+  double r0, r1;
+};
+
+__device__ __forceinline__ void project(const double *__restrict__ cam,
+                                        const double *__restrict__ T,
+                                        const double X0, const double X1,
+                                        const double X2, const double u,
+                                        const double v, ObsGeom &g) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    g.Xij[r] = (T[r * 3 + 0] * X0 + T[r * 3 + 1] * X1 + T[r * 3 + 2] * X2) +
+               T[9 + r];
+  const double *Rc = cam + 4;
+  const double *tc = cam + 13;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    g.Xc[r] = (Rc[r * 3 + 0] * g.Xij[0] + Rc[r * 3 + 1] * g.Xij[1] +
+               Rc[r * 3 + 2] * g.Xij[2]) +
+              tc[r];
+  const double invz = 1.0 / g.Xc[2];
+  g.r0 = cam[0] * (g.Xc[0] * invz) + cam[2] - u;
+  g.r1 = cam[1] * (g.Xc[1] * invz) + cam[3] - v;
+}
+
+// Huber-like weight (reference :763-766) and G = dpi/dXc * R_cj (:770-787).
+__device__ __forceinline__ void weight_and_G(const double *__restrict__ cam,
+                                             const ObsGeom &g, double huber,
+                                             double &w, double G[6]) {
+  const double invz = 1.0 / g.Xc[2];
+  const double fxinvz = cam[0] * invz, fyinvz = cam[1] * invz;
+  const double xinvz = g.Xc[0] * invz, yinvz = g.Xc[1] * invz;
+  const double fx_xinvz2 = fxinvz * xinvz, fy_yinvz2 = fyinvz * yinvz;
+  const double absr = fabs(g.r0) + fabs(g.r1);
+  w = (absr > huber) ? (huber / absr) : 1.0;
+  const double *Rc = cam + 4;
+  G[0] = fxinvz * Rc[0] + (-fx_xinvz2) * Rc[6];
+  G[1] = fxinvz * Rc[1] + (-fx_xinvz2) * Rc[7];
+  G[2] = fxinvz * Rc[2] + (-fx_xinvz2) * Rc[8];
+  G[3] = fyinvz * Rc[3] + (-fy_yinvz2) * Rc[6];
+  G[4] = fyinvz * Rc[4] + (-fy_yinvz2) * Rc[7];
+  G[5] = fyinvz * Rc[5] + (-fy_yinvz2) * Rc[8];
+}
+
+// Q = [G, G * (-[Xij]x)]  (reference :797-800), 2x6 row-major
+__device__ __forceinline__ void make_Q(const double G[6], const double Xij[3],
+                                       double Q[12]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const double g0 = G[r * 3 + 0], g1 = G[r * 3 + 1], g2 = G[r * 3 + 2];
+    Q[r * 6 + 0] = g0;
+    Q[r * 6 + 1] = g1;
+    Q[r * 6 + 2] = g2;
+    Q[r * 6 + 3] = g2 * Xij[1] - g1 * Xij[2];
+    Q[r * 6 + 4] = g0 * Xij[2] - g2 * Xij[0];
+    Q[r * 6 + 5] = g1 * Xij[0] - g0 * Xij[1];
+  }
+}
+
+// R = G * R_jw (reference :814), 2x3 row-major
+__device__ __forceinline__ void make_R(const double G[6],
+                                       const double *__restrict__ T,
+                                       double Rm[6]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Rm[r * 3 + c] = G[r * 3 + 0] * T[0 * 3 + c] + G[r * 3 + 1] * T[1 * 3 + c] +
+                      G[r * 3 + 2] * T[2 * 3 + c];
+}
+
+// Symmetric 3x3 inverse by diagonally pivoted LDL^T with D pseudo-inverted —
+// the behaviour of Eigen's C.ldlt().solve(I) (reference :854): an all-zero
+// C_i (never-observed landmark) yields Cinv = 0, not NaN.
+// c = {c00 c01 c02 c11 c12 c22}; out in the same order.
+__device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
+  double a00 = c[0], a01 = c[1], a02 = c[2], a11 = c[3], a12 = c[4], a22 = c[5];
+  // pivot order = selection by |diag| (left-looking: untouched diagonal)
+  int s0 = 0;  // 0: none, 1: swap(0,1), 2: swap(0,2)
+  {
+    double m = fabs(a00);
+    if (fabs(a11) > m) {
+      m = fabs(a11);
+      s0 = 1;
+    }
+    if (fabs(a22) > m) s0 = 2;
+  }
+  double t;
+  if (s0 == 1) {
+    t = a00; a00 = a11; a11 = t;
+    t = a02; a02 = a12; a12 = t;
+  } else if (s0 == 2) {
+    t = a00; a00 = a22; a22 = t;
+    t = a01; a01 = a12; a12 = t;
+  }
+  const bool s1 = fabs(a22) > fabs(a11);
+  if (s1) {
+    t = a11; a11 = a22; a22 = t;
+    t = a01; a01 = a02; a02 = t;
+  }
+  double b00 = 0, b01 = 0, b02 = 0, b11 = 0, b12 = 0, b22 = 0;
+  const double d0 = a00;
+  if (fabs(d0) > 0.0) {
+    const double l10 = a01 / d0, l20 = a02 / d0;
+    const double tmp0 = d0 * l10;
+    const double d1 = a11 - l10 * tmp0;
+    double l21 = a12 - l20 * tmp0;
+    if (fabs(d1) > 0.0) l21 /= d1;
+    const double d2 = a22 - (l20 * (d0 * l20) + l21 * (d1 * l21));
+    const double tol = 2.2250738585072014e-308;
+    const double i0 = (fabs(d0) > tol) ? 1.0 / d0 : 0.0;
+    const double i1 = (fabs(d1) > tol) ? 1.0 / d1 : 0.0;
+    const double i2 = (fabs(d2) > tol) ? 1.0 / d2 : 0.0;
+    // columns of the inverse: solve L D L^T x = e_c
+    // e0: z = (1, -l10, -l20 + l21 l10)
+    {
+      const double z0 = 1.0, z1 = -l10 * z0, z2 = -l20 * z0 - l21 * z1;
+      const double w0 = z0 * i0, w1 = z1 * i1, w2 = z2 * i2;
+      const double x2 = w2, x1 = w1 - l21 * x2, x0 = w0 - l10 * x1 - l20 * x2;
+      b00 = x0;
+      (void)x1;
+      (void)x2;
+    }
+    {
+      const double z1 = 1.0, z2 = -l21 * z1;
+      const double w1 = z1 * i1, w2 = z2 * i2;
+      const double x2 = w2, x1 = w1 - l21 * x2, x0 = -l10 * x1 - l20 * x2;
+      b01 = x0;
+      b11 = x1;
+    }
+    {
+      const double w2 = i2;
+      const double x2 = w2, x1 = -l21 * x2, x0 = -l10 * x1 - l20 * x2;
+      b02 = x0;
+      b12 = x1;
+      b22 = x2;
+    }
+  }
+  // undo the symmetric permutations (involutions, reverse order)
+  if (s1) {
+    t = b11; b11 = b22; b22 = t;
+    t = b01; b01 = b02; b02 = t;
+  }
+  if (s0 == 1) {
+    t = b00; b00 = b11; b11 = t;
+    t = b02; b02 = b12; b12 = t;
+  } else if (s0 == 2) {
+    t = b00; b00 = b22; b22 = t;
+    t = b01; b01 = b12; b12 = t;
+  }
+  o[0] = b00; o[1] = b01; o[2] = b02; o[3] = b11; o[4] = b12; o[5] = b22;
+}
+
+// --------------------------------------------------------------------------
+// cost: sum over observations of ||r||  (reference :381-433)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
+  if (d.ctrl->done) return;
+  __shared__ double sm[4];
+  const int buf = d.ctrl->cur ^ sel;
+  const double *__restrict__ poses = d.poses[buf];
+  const double *__restrict__ pts = d.pts[buf];
+  double acc = 0.0;
+  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < d.n_obs;
+       s += (int64_t)gridDim.x * kBlock) {
+    const int4 id = d.obs_idx[s];
+    const double2 uv = d.obs_uv[s];
+    const double *X = pts + (size_t)id.z * 3;
+    ObsGeom g;
+    project(d.cams + id.x * 16, poses + (size_t)id.y * 12, X[0], X[1], X[2],
+            uv.x, uv.y, g);
+    acc += sqrt(g.r0 * g.r0 + g.r1 * g.r1);
+  }
+  const double tot = block_sum(acc, sm);
+  if (threadIdx.x == 0) d.cost_part[blockIdx.x] = tot;
+}
+
+// --------------------------------------------------------------------------
+// landmark side of the linearisation, one thread per optimisable landmark
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
+  if (d.ctrl->done) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= d.M) return;
+  const int buf = d.ctrl->cur;
+  const double huber = d.ctrl->huber;
+  const double lp1 = 1.0 + d.ctrl->lambda;
+  const double *__restrict__ poses = d.poses[buf];
+  const double *X = d.pts[buf] + (size_t)i * 3;
+  const double X0 = X[0], X1 = X[1], X2 = X[2];
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  double b0 = 0, b1 = 0, b2 = 0;
+  const int64_t s0 = d.lm_obs_ptr[i], s1 = d.lm_obs_ptr[i + 1];
+  for (int64_t s = s0; s < s1; ++s) {
+    const int4 id = d.obs_idx[s];
+    const double2 uv = d.obs_uv[s];
+    const double *cam = d.cams + id.x * 16;
+    const double *T = poses + (size_t)id.y * 12;
+    ObsGeom g;
+    project(cam, T, X0, X1, X2, uv.x, uv.y, g);
+    double w, G[6], Rm[6];
+    weight_and_G(cam, g, huber, w, G);
+    make_R(G, T, Rm);
+    // reference :503-517, :817-823
+    c00 += w * (Rm[0] * Rm[0] + Rm[3] * Rm[3]);
+    c01 += w * (Rm[0] * Rm[1] + Rm[3] * Rm[4]);
+    c02 += w * (Rm[0] * Rm[2] + Rm[3] * Rm[5]);
+    c11 += w * (Rm[1] * Rm[1] + Rm[4] * Rm[4]);
+    c12 += w * (Rm[1] * Rm[2] + Rm[4] * Rm[5]);
+    c22 += w * (Rm[2] * Rm[2] + Rm[5] * Rm[5]);
+    const double wr0 = w * g.r0, wr1 = w * g.r1;
+    b0 -= Rm[0] * wr0 + Rm[3] * wr1;
+    b1 -= Rm[1] * wr0 + Rm[4] * wr1;
+    b2 -= Rm[2] * wr0 + Rm[5] * wr1;
+    if (id.w >= 0) {
+      // B_ji = w Q^T R, kept only from the last-inserted observation of the
+      // pair (reference :826)
+      double Q[12];
+      make_Q(G, g.Xij, Q);
+      double *Wp = d.W + (size_t)id.w * 18;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          Wp[r * 3 + c] = w * (Q[r] * Rm[c] + Q[6 + r] * Rm[3 + c]);
+    }
+  }
+  // reference :846-856
+  double cd[6] = {c00 * lp1, c01, c02, c11 * lp1, c12, c22 * lp1};
+  double ci[6];
+  ldlt3_inverse(cd, ci);
+  double *Co = d.Cd + (size_t)i * 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Co[k] = cd[k];
+  double *bo = d.b + (size_t)i * 3;
+  bo[0] = b0;
+  bo[1] = b1;
+  bo[2] = b2;
+  double *Io = d.Cinv + (size_t)i * 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Io[k] = ci[k];
+  double *cb = d.Cinvb + (size_t)i * 3;
+  cb[0] = ci[0] * b0 + ci[1] * b1 + ci[2] * b2;
+  cb[1] = ci[1] * b0 + ci[3] * b1 + ci[4] * b2;
+  cb[2] = ci[2] * b0 + ci[4] * b1 + ci[5] * b2;
+}
+
+// --------------------------------------------------------------------------
+// pose side of the linearisation: one block per chunk of one pose's
+// observations -> 27 partial sums (21 upper A + 6 of Q^T w r)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ double sm[4];
+  const int ch = blockIdx.x;
+  const int buf = d.ctrl->cur;
+  const double huber = d.ctrl->huber;
+  const int j = d.achunk_pose[ch];
+  const double *__restrict__ pts = d.pts[buf];
+  const double *T = d.poses[buf] + (size_t)j * 12;
+  double Tl[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Tl[k] = T[k];
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  const int64_t e = d.achunk_end[ch];
+  for (int64_t s = d.achunk_begin[ch] + threadIdx.x; s < e; s += kBlock) {
+    const int4 id = d.pobs_idx[s];
+    const double2 uv = d.pobs_uv[s];
+    const double *cam = d.cams + id.x * 16;
+    const double *X = pts + (size_t)id.z * 3;
+    ObsGeom g;
+    project(cam, Tl, X[0], X[1], X[2], uv.x, uv.y, g);
+    double w, G[6], Q[12];
+    weight_and_G(cam, g, huber, w, G);
+    make_Q(G, g.Xij, Q);
+    // reference :519-556
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c)
+        acc[k++] += (w * Q[r]) * Q[c] + (w * Q[6 + r]) * Q[6 + c];
+    const double wr0 = w * g.r0, wr1 = w * g.r1;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[21 + c] += Q[c] * wr0 + Q[6 + c] * wr1;
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const double tot = block_sum(acc[k], sm);
+    if (threadIdx.x == 0) d.Apart[(size_t)ch * 27 + k] = tot;
+  }
+}
+
+// V_ji = W_ji Cinv_i   (reference :862)
+__global__ __launch_bounds__(kBlock) void k_pair_bcinv(DevProblem d) {
+  if (d.ctrl->done) return;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= d.P) return;
+  const int i = d.pair_lm[p];
+  const double *ci = d.Cinv + (size_t)i * 6;
+  const double i00 = ci[0], i01 = ci[1], i02 = ci[2], i11 = ci[3], i12 = ci[4],
+               i22 = ci[5];
+  const double *Wp = d.W + (size_t)p * 18;
+  double *Vp = d.V + (size_t)p * 18;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const double w0 = Wp[r * 3 + 0], w1 = Wp[r * 3 + 1], w2 = Wp[r * 3 + 2];
+    Vp[r * 3 + 0] = w0 * i00 + w1 * i01 + w2 * i02;
+    Vp[r * 3 + 1] = w0 * i01 + w1 * i11 + w2 * i12;
+    Vp[r * 3 + 2] = w0 * i02 + w1 * i12 + w2 * i22;
+  }
+}
+
+// partial sums of BCinv_b_j = sum_i V_ji b_i over a chunk of pose j's pairs
+__global__ __launch_bounds__(kBlock) void k_rhs_partial(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ double sm[4];
+  const int ch = blockIdx.x;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const int64_t e = d.rchunk_end[ch];
+  for (int64_t s = d.rchunk_begin[ch] + threadIdx.x; s < e; s += kBlock) {
+    const int64_t p = d.ppair[s];
+    const int i = d.pair_lm[p];
+    const double *Vp = d.V + (size_t)p * 18;
+    const double *bi = d.b + (size_t)i * 3;
+    const double b0 = bi[0], b1 = bi[1], b2 = bi[2];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      acc[r] += Vp[r * 3 + 0] * b0 + Vp[r * 3 + 1] * b1 + Vp[r * 3 + 2] * b2;
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const double tot = block_sum(acc[r], sm);
+    if (threadIdx.x == 0) d.rpart[(size_t)ch * 6 + r] = tot;
+  }
+}
+
+// A_j (mirrored, damped) and a_j from the partial sums.
+// One thread per (pose, component): 21 upper + 6 gradient entries.
+__global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
+  if (d.ctrl->done) return;
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= d.N * 27) return;
+  const int j = t / 27, e = t % 27;
+  double s = 0.0;
+  for (int ch = d.pose_achunk_ptr[j]; ch < d.pose_achunk_ptr[j + 1]; ++ch)
+    s += d.Apart[(size_t)ch * 27 + e];
+  if (e < 21) {
+    // upper-triangle index -> (r, c)
+    int r = 0, k = e;
+    while (k >= 6 - r) {
+      k -= 6 - r;
+      ++r;
+    }
+    const int c = r + k;
+    if (r == c) s *= (1.0 + d.ctrl->lambda);  // reference :833-844
+    d.A[(size_t)j * 36 + r * 6 + c] = s;
+    d.A[(size_t)j * 36 + c * 6 + r] = s;
+  } else {
+    const int r = e - 21;
+    d.a[(size_t)j * 6 + r] = -s;  // reference :809  a_j -= Q^T (w r)
+  }
+}
+
+// rhs_j = a_j - BCinv_b_j (reference :887-888); rides as row `npad` of the
+// dense system.  One thread per (pose, component).
+__global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
+  if (d.ctrl->done) return;
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= d.N * 6) return;
+  const int j = t / 6, r = t % 6;
+  double bc = 0.0;
+  for (int ch = d.pose_rchunk_ptr[j]; ch < d.pose_rchunk_ptr[j + 1]; ++ch)
+    bc += d.rpart[(size_t)ch * 6 + r];
+  d.L[(size_t)(6 * j + r) * d.ld + d.npad] = d.a[(size_t)j * 6 + r] - bc;
+}
+
+// partial sums of BCinvBt_jk over a chunk of the (j,k) block's triples:
+// one wave per chunk (reference :866-870)
+__global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
+  if (d.ctrl->done) return;
+  const int ch = blockIdx.x;
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  const int64_t e = d.tchunk_end[ch];
+  for (int64_t t = d.tchunk_begin[ch] + threadIdx.x; t < e; t += 64) {
+    const double *Vp = d.V + (size_t)d.tri_p[t] * 18;
+    const double *Wq = d.W + (size_t)d.tri_q[t] * 18;
+    double v[18], w[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      v[k] = Vp[k];
+      w[k] = Wq[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        acc[r * 6 + c] += v[r * 3 + 0] * w[c * 3 + 0] +
+                          v[r * 3 + 1] * w[c * 3 + 1] +
+                          v[r * 3 + 2] * w[c * 3 + 2];
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    const double tot = wave_sum(acc[k]);
+    if (threadIdx.x == 0) d.spart[(size_t)ch * 36 + k] = tot;
+  }
+}
+
+// S_jk = delta_jk A_j - BCinvBt_jk, scattered into the dense column-major
+// lower matrix (reference :878-902). One thread per (block, entry).
+__global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
+  if (d.ctrl->done) return;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= d.B * 36) return;
+  const int64_t blk = t / 36;
+  const int e = (int)(t % 36);
+  const int r = e / 6, c = e % 6;
+  const int j = d.sblk_j[blk], k = d.sblk_k[blk];
+  double s = 0.0;
+  for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
+    s += d.spart[(size_t)ch * 36 + e];
+  const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
+  // element (row 6k+c, col 6j+r) of the lower triangle holds S_jk[r][c]
+  d.L[(size_t)(6 * j + r) * d.ld + (6 * k + c)] = val;
+}
+
+// y_i, trial point, landmark-side model terms and |y_i|
+__global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ double sm[4];
+  const int cur = d.ctrl->cur;
+  const double *__restrict__ Xc = d.pts[cur];
+  double *__restrict__ Xt = d.pts[cur ^ 1];
+  double est = 0.0, nrm = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.M;
+       i += gridDim.x * kBlock) {
+    double av0 = 0, av1 = 0, av2 = 0;  // sum_j V_ji^T x_j
+    double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
+    for (int64_t p = d.lm_pair_ptr[i]; p < d.lm_pair_ptr[i + 1]; ++p) {
+      const double *xj = d.x + (size_t)d.pair_pose[p] * 6;
+      const double *Vp = d.V + (size_t)p * 18;
+      const double *Wp = d.W + (size_t)p * 18;
+      double s0 = 0, s1 = 0, s2 = 0, u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double xr = xj[r];
+        s0 += Vp[r * 3 + 0] * xr;
+        s1 += Vp[r * 3 + 1] * xr;
+        s2 += Vp[r * 3 + 2] * xr;
+        u0 += Wp[r * 3 + 0] * xr;
+        u1 += Wp[r * 3 + 1] * xr;
+        u2 += Wp[r * 3 + 2] * xr;
+      }
+      av0 += s0; av1 += s1; av2 += s2;
+      bx0 += u0; bx1 += u1; bx2 += u2;
+    }
+    const double *cb = d.Cinvb + (size_t)i * 3;
+    const double y0 = cb[0] - av0, y1 = cb[1] - av1, y2 = cb[2] - av2;
+    double *yo = d.y + (size_t)i * 3;
+    yo[0] = y0; yo[1] = y1; yo[2] = y2;
+    const double *Xi = Xc + (size_t)i * 3;
+    double *Xo = Xt + (size_t)i * 3;
+    Xo[0] = Xi[0] + y0;
+    Xo[1] = Xi[1] + y1;
+    Xo[2] = Xi[2] + y2;
+    // reference :443-452 with the damped C_i
+    const double *bi = d.b + (size_t)i * 3;
+    const double *C = d.Cd + (size_t)i * 6;
+    double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;
+    const double q0 = y0 * C[0] + y1 * C[1] + y2 * C[2];
+    const double q1 = y0 * C[1] + y1 * C[3] + y2 * C[4];
+    const double q2 = y0 * C[2] + y1 * C[4] + y2 * C[5];
+    e += q0 * y0 + q1 * y1 + q2 * y2;
+    e += 2.0 * (y0 * bx0 + y1 * bx1 + y2 * bx2);
+    est += e;
+    nrm += sqrt(y0 * y0 + y1 * y1 + y2 * y2);
+  }
+  const double t0 = block_sum(est, sm);
+  const double t1 = block_sum(nrm, sm);
+  if (threadIdx.x == 0) {
+    d.lm_part[2 * blockIdx.x + 0] = t0;
+    d.lm_part[2 * blockIdx.x + 1] = t1;
+  }
+}
+
+// se3 exponential (reference :1046-1082) composed onto T_jw (:487-494),
+// pose-side model terms (:437-441) and sum |x_j| (:962).  Single block.
+__global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ double sm[4];
+  const int cur = d.ctrl->cur;
+  const double *__restrict__ Tc = d.poses[cur];
+  double *__restrict__ Tt = d.poses[cur ^ 1];
+  double est = 0.0, nrm = 0.0;
+  for (int j = threadIdx.x; j < d.N; j += kBlock) {
+    const double *xj = d.x + (size_t)j * 6;
+    const double v0 = xj[0], v1 = xj[1], v2 = xj[2];
+    const double w0 = xj[3], w1 = xj[4], w2 = xj[5];
+    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    const double wx[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double wx2[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        wx2[r * 3 + c] = wx[r * 3 + 0] * wx[0 * 3 + c] +
+                         wx[r * 3 + 1] * wx[1 * 3 + c] +
+                         wx[r * 3 + 2] * wx[2 * 3 + c];
+    double ca, cb, va, vb;
+    if (theta < 1e-7) {
+      ca = 1.0;
+      cb = 0.5;
+      va = 0.5;
+      vb = 0.33333333333333333333333333;
+    } else {
+      const double st = sin(theta), ct = cos(theta);
+      ca = st / theta;
+      cb = (1.0 - ct) / (theta * theta);
+      va = cb;
+      vb = (theta - st) / (theta * theta * theta);
+    }
+    double dR[9], V[9], dt[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double id = (k % 4 == 0) ? 1.0 : 0.0;
+      dR[k] = id + ca * wx[k] + cb * wx2[k];
+      V[k] = id + va * wx[k] + vb * wx2[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      dt[r] = V[r * 3 + 0] * v0 + V[r * 3 + 1] * v1 + V[r * 3 + 2] * v2;
+    const double *T = Tc + (size_t)j * 12;
+    double *To = Tt + (size_t)j * 12;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        To[r * 3 + c] = dR[r * 3 + 0] * T[0 * 3 + c] +
+                        dR[r * 3 + 1] * T[1 * 3 + c] +
+                        dR[r * 3 + 2] * T[2 * 3 + c];
+      To[9 + r] = dR[r * 3 + 0] * T[9] + dR[r * 3 + 1] * T[10] +
+                  dR[r * 3 + 2] * T[11] + dt[r];
+    }
+    const double *aj = d.a + (size_t)j * 6;
+    const double *Aj = d.A + (size_t)j * 36;
+    double e = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) e += aj[r] * xj[r];
+    double q = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double rowc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) rowc += xj[r] * Aj[r * 6 + c];
+      q += rowc * xj[c];
+    }
+    est += e + q;
+    nrm += sqrt(v0 * v0 + v1 * v1 + v2 * v2 + w0 * w0 + w1 * w1 + w2 * w2);
+  }
+  const double t0 = block_sum(est, sm);
+  const double t1 = block_sum(nrm, sm);
+  if (threadIdx.x == 0) {
+    d.pose_part[0] = t0;
+    d.pose_part[1] = t1;
+  }
+}
+
+// Reduce the block partials into the exchange scalars.
+//   mode 0: scal[0] = cost only (initial cost)
+//   mode 1: scal[0] = trial cost, scal[1] = model estimate, scal[2] = sum|y|
+__global__ __launch_bounds__(kBlock) void k_scalars(DevProblem d, int mode) {
+  if (d.ctrl->done) return;
+  __shared__ double sm[4];
+  double c = 0.0, e = 0.0, n = 0.0;
+  for (int k = threadIdx.x; k < kCostGrid; k += kBlock) c += d.cost_part[k];
+  if (mode == 1)
+    for (int k = threadIdx.x; k < kLmGrid; k += kBlock) {
+      e += d.lm_part[2 * k + 0];
+      n += d.lm_part[2 * k + 1];
+    }
+  const double tc = block_sum(c, sm);
+  const double te = block_sum(e, sm);
+  const double tn = block_sum(n, sm);
+  if (threadIdx.x == 0) {
+    d.scal[0] = tc;
+    d.scal[1] = (mode == 1) ? te + d.pose_part[0] : 0.0;
+    d.scal[2] = (mode == 1) ? tn : 0.0;
+    d.scal[3] = 0.0;
+  }
+}
+
+__global__ void k_init_ctrl_cost(DevProblem d) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  d.ctrl->prev_cost = d.scal[0];
+  d.ctrl->t_last = wall_clock64();
+}
+
+// Trust region, convergence and iteration log (reference :928-1007).
+__global__ void k_control(DevProblem d) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  DevCtrl *c = d.ctrl;
+  if (c->done) return;
+  const double current_cost = d.scal[0];
+  const double model = -d.scal[1];
+  const double previous_cost = c->prev_cost;
+  const double rho = (current_cost - previous_cost) * 100.0 / model;
+  int status;
+  if (rho > 0.25) {
+    status = 0;
+    c->cur ^= 1;  // the trial buffer becomes the accepted one
+  } else {
+    status = 2;   // keep the reserved parameters (reference :943)
+  }
+  double lambda = c->lambda;
+  if (rho > 0.5) {
+    lambda = fmax(1e-10, lambda * c->dec_ratio);
+    status = 1;
+  } else if (rho <= 0.25) {
+    lambda = fmin(100.0, lambda * c->inc_ratio);
+  }
+  c->lambda = lambda;
+  const double n_obs = (double)d.n_obs_global;
+  const double average_error = current_cost / n_obs;
+  const double cost_change = fabs(current_cost - previous_cost);
+  const double total_step = d.scal[2] + d.pose_part[1];
+  const double avg_step = total_step / (double)(d.N + d.M_global);
+  bool conv = (avg_step < c->thr_step) || (cost_change < c->thr_cost);
+  if (c->iter >= c->max_iter - 1) conv = false;
+  const unsigned long long now = wall_clock64();
+  if (c->iter < d.log_cap) {
+    DevIterRec &I = d.log[c->iter];
+    I.cost = current_cost;
+    I.cost_change = cost_change;
+    I.average_reprojection_error = average_error;
+    I.abs_gradient = 0.0;
+    I.abs_step = avg_step;
+    I.damping_term = lambda;
+    I.iter_time_ms = (double)(now - c->t_last) * 1e-5;  // 100 MHz clock
+    I.iteration_status = status;
+    I.pad_ = 0;
+    I.rho = rho;
+    I.model_change = model;
+    I.trial_cost = current_cost;
+    if (status == 2) {  // reference :995-1000
+      I.cost = previous_cost;
+      I.cost_change = 0.0;
+      I.average_reprojection_error = sqrt(previous_cost / n_obs);
+    }
+  }
+  c->t_last = now;
+  c->prev_cost = current_cost;  // even when SKIPPED (reference :1005)
+  c->iter += 1;
+  c->converged = conv ? 1 : 0;
+  if (conv || c->iter >= c->max_iter) c->done = 1;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+void launch_cost(const DevProblem &d, int sel, hipStream_t s) {
+  hipLaunchKernelGGL(k_cost, dim3(kCostGrid), dim3(kBlock), 0, s, d, sel);
+}
+
+void launch_linearize(const DevProblem &d, hipStream_t s) {
+  if (d.M > 0)
+    hipLaunchKernelGGL(k_lin_landmarks, dim3(cdiv(d.M, kBlock)), dim3(kBlock),
+                       0, s, d);
+  if (d.n_achunk > 0)
+    hipLaunchKernelGGL(k_lin_poses, dim3(d.n_achunk), dim3(kBlock), 0, s, d);
+  if (d.N > 0)
+    hipLaunchKernelGGL(k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)),
+                       dim3(kBlock), 0, s, d);
+}
+
+void launch_schur(const DevProblem &d, hipStream_t s) {
+  launch_dense_init(d.L, d.npad, d.ld, 6 * d.N, &d.ctrl->done, s);
+  if (d.P > 0)
+    hipLaunchKernelGGL(k_pair_bcinv, dim3(cdiv(d.P, kBlock)), dim3(kBlock), 0,
+                       s, d);
+  if (d.n_rchunk > 0)
+    hipLaunchKernelGGL(k_rhs_partial, dim3(d.n_rchunk), dim3(kBlock), 0, s, d);
+  if (d.N > 0)
+    hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)),
+                       dim3(kBlock), 0, s, d);
+  if (d.n_tchunk > 0)
+    hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
+  if (d.B > 0)
+    hipLaunchKernelGGL(k_schur_final, dim3(cdiv(d.B * 36, kBlock)),
+                       dim3(kBlock), 0, s, d);
+}
+
+void launch_backsub_update(const DevProblem &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_backsub_update, dim3(kLmGrid), dim3(kBlock), 0, s, d);
+  hipLaunchKernelGGL(k_pose_update, dim3(1), dim3(kBlock), 0, s, d);
+}
+
+void launch_scalars(const DevProblem &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(kBlock), 0, s, d, 1);
+}
+
+void launch_control(const DevProblem &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, s, d);
+}
+
+void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_ctrl_cost, dim3(1), dim3(64), 0, s, d);
+}
+
+// exposed for ba_api: initial-cost scalar reduction (mode 0)
+void launch_scalars_cost_only(const DevProblem &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(kBlock), 0, s, d, 0);
+}
+
+}  // namespace ba

@@ -1,0 +1,104 @@
+// ba_plan.h — host-side problem plan for the HIP bundle-adjustment path.
+//
+// Replaces the reference's FinalizeParameters / SetProblemSize / connectivity
+// build (reference core/full_bundle_adjustment_solver.cpp:182-206, :243-308,
+// :668-700).  Instead of pointer-keyed hash maps and dense N x M block grids
+// it produces flat, sorted index arrays that the kernels stream:
+//   * landmark-major observation list (C/b/W side),
+//   * pose-major observation list (A/a side),
+//   * (landmark, pose) pair CSR for the cross blocks W_ji,
+//   * pose-major pair permutation (rhs side),
+//   * (j,k)-sorted triple list for the Schur complement blocks.
+#ifndef BA_PLAN_H_
+#define BA_PLAN_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace ba {
+
+struct PlanInput {
+  int n_cam = 0;
+  int n_pose = 0;
+  const uint8_t *pose_fixed = nullptr;
+  int n_pt = 0;
+  const uint8_t *pt_fixed = nullptr;
+  int64_t n_obs = 0;
+  const int32_t *obs_cam = nullptr;
+  const int32_t *obs_pose = nullptr;
+  const int32_t *obs_pt = nullptr;
+  const double *obs_uv = nullptr;
+  int rank = 0;
+  int world = 1;
+};
+
+// Work-item granularities (shared with the kernels).
+constexpr int kPoseChunk = 1024;   // observations per A/a partial-sum item
+constexpr int kRhsChunk = 1024;    // pairs per rhs partial-sum item
+constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
+
+struct Plan {
+  // ---- sizes ----
+  int n_cam = 0;
+  int n_pose = 0;        // all poses (replicated on every shard)
+  int N = 0;             // optimised poses
+  int n_pt_global = 0;   // all points of the full problem
+  int M_global = 0;      // optimised points of the full problem
+  int n_pt = 0;          // points owned by this shard (opt first, then fixed)
+  int M = 0;             // optimised points owned by this shard
+  int64_t n_obs_global = 0;
+  int64_t n_obs = 0;     // observations of owned points
+  int64_t n_obs_opt = 0; // ... whose point is optimisable (prefix of list)
+  int64_t P = 0;         // (landmark, pose) pairs, both optimisable
+  int64_t n_pobs = 0;    // observations whose pose is optimisable
+  int64_t T = 0;         // Schur triples
+  int64_t B = 0;         // non-zero upper blocks of S (incl. all diagonals)
+
+  // ---- index maps ----
+  std::vector<int32_t> pose_int_of_user, pose_user_of_int;  // n_pose
+  std::vector<int32_t> jopt_of_user;   // user pose -> opt index (input order)
+  std::vector<int32_t> pt_int_of_user; // n_pt_global, -1 if not owned
+  std::vector<int32_t> pt_user_of_int; // n_pt
+  std::vector<int32_t> iopt_of_user;   // user point -> GLOBAL opt idx or -1
+  std::vector<int32_t> owner;          // n_pt_global owner rank
+
+  // ---- landmark-major observations ----
+  std::vector<int32_t> obs_idx;   // n_obs*4: cam, pose_int, pt_int, pair|-1
+  std::vector<double> obs_uv;     // n_obs*2
+  std::vector<int64_t> lm_obs_ptr;   // M+1
+  // ---- pairs ----
+  std::vector<int64_t> lm_pair_ptr;  // M+1
+  std::vector<int32_t> pair_pose;    // P (internal pose, < N)
+  std::vector<int32_t> pair_lm;      // P (internal point, < M)
+  // ---- pose-major observations (optimisable poses only) ----
+  std::vector<int32_t> pobs_idx;  // n_pobs*4: cam, pose_int, pt_int, 0
+  std::vector<double> pobs_uv;    // n_pobs*2
+  std::vector<int64_t> pose_obs_ptr;     // N+1
+  std::vector<int32_t> achunk_pose;      // per A/a work item
+  std::vector<int64_t> achunk_begin;     // nchunk+1 style: begin of each
+  std::vector<int64_t> achunk_end;
+  std::vector<int32_t> pose_achunk_ptr;  // N+1
+  // ---- pose-major pair permutation ----
+  std::vector<int64_t> ppair;            // P pair ids sorted by (pose, lm)
+  std::vector<int32_t> rchunk_pose;
+  std::vector<int64_t> rchunk_begin, rchunk_end;
+  std::vector<int32_t> pose_rchunk_ptr;  // N+1
+  // ---- Schur triples ----
+  std::vector<int32_t> sblk_j, sblk_k;   // B
+  std::vector<int64_t> sblk_tri_ptr;     // B+1
+  std::vector<int64_t> tri_p, tri_q;     // T : pair ids (pose j side, k side)
+  std::vector<int32_t> tchunk_blk;       // per Schur work item
+  std::vector<int64_t> tchunk_begin, tchunk_end;
+  std::vector<int32_t> sblk_tchunk_ptr;  // B+1
+};
+
+// Owner rank of every point: locality order (first observing optimised pose,
+// then input index), contiguous chunks balanced by observation count.
+void partition_points(const PlanInput &in, std::vector<int32_t> &owner);
+
+// Returns empty string on success, otherwise an error message.
+std::string build_plan(const PlanInput &in, Plan &plan);
+
+}  // namespace ba
+#endif

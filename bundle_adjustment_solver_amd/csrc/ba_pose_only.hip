@@ -1,0 +1,303 @@
+// ba_pose_only.hip — pose-only monocular 6-DoF Gauss-Newton, fp32, gfx950.
+//
+// Replaces PoseOnlyBundleAdjustmentSolver::Solve_Monocular_6Dof (reference
+// core/pose_only_bundle_adjustment_solver.cpp:8-170 with helpers :1338-1452,
+// :1147-1200, :1280-1316).  The whole GN loop runs inside ONE persistent
+// workgroup launch (the problem is 10 k points ~ 200 KB: launch / PCIe latency
+// dominates, not bandwidth): per iteration every thread linearises its points,
+// the 21+6+1 sums are reduced through shuffles + LDS, thread 0 solves the 6x6
+// system with the pivoted LDL^T the reference gets from Eigen and composes the
+// se3 exponential onto the pose held in LDS.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/ba_hip.h"
+#include "ba_device.h"
+
+namespace ba {
+
+namespace {
+
+constexpr int kPoThreads = 1024;
+constexpr int kPoWaves = kPoThreads / 64;
+constexpr int kNred = 28;  // 21 upper H + 6 g + 1 err
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Eigen-style pivoted LDL^T solve of a 6x6 system in fp32 (thread 0 only).
+__device__ void ldlt6_solve(float *m /*36, row-major, lower used*/, float *d) {
+  int tr[6];
+#define AT(r, c) m[(r) * 6 + (c)]
+  bool early = false;
+  for (int k = 0; k < 6 && !early; ++k) {
+    int big = k;
+    float bigv = fabsf(AT(k, k));
+    for (int i = k + 1; i < 6; ++i)
+      if (fabsf(AT(i, i)) > bigv) {
+        bigv = fabsf(AT(i, i));
+        big = i;
+      }
+    tr[k] = big;
+    if (k != big) {
+      const int s = 6 - big - 1;
+      for (int c = 0; c < k; ++c) {
+        float t = AT(k, c); AT(k, c) = AT(big, c); AT(big, c) = t;
+      }
+      for (int r = 0; r < s; ++r) {
+        float t = AT(big + 1 + r, k);
+        AT(big + 1 + r, k) = AT(big + 1 + r, big);
+        AT(big + 1 + r, big) = t;
+      }
+      {
+        float t = AT(k, k); AT(k, k) = AT(big, big); AT(big, big) = t;
+      }
+      for (int i = k + 1; i < big; ++i) {
+        float t = AT(i, k); AT(i, k) = AT(big, i); AT(big, i) = t;
+      }
+    }
+    const int rs = 6 - k - 1;
+    float tmp[6];
+    if (k > 0) {
+      float acc = 0.0f;
+      for (int c = 0; c < k; ++c) {
+        tmp[c] = AT(c, c) * AT(k, c);
+        acc += AT(k, c) * tmp[c];
+      }
+      AT(k, k) -= acc;
+      for (int r = 0; r < rs; ++r) {
+        float s2 = 0.0f;
+        for (int c = 0; c < k; ++c) s2 += AT(k + 1 + r, c) * tmp[c];
+        AT(k + 1 + r, k) -= s2;
+      }
+    }
+    const float akk = AT(k, k);
+    const bool valid = fabsf(akk) > 0.0f;
+    if (k == 0 && !valid) {
+      for (int j = 0; j < 6; ++j) tr[j] = j;
+      early = true;
+      break;
+    }
+    if (rs > 0 && valid)
+      for (int r = 0; r < rs; ++r) AT(k + 1 + r, k) /= akk;
+  }
+  for (int i = 0; i < 6; ++i)
+    if (tr[i] != i) { float t = d[i]; d[i] = d[tr[i]]; d[tr[i]] = t; }
+  for (int i = 0; i < 6; ++i) {
+    float s = d[i];
+    for (int c = 0; c < i; ++c) s -= AT(i, c) * d[c];
+    d[i] = s;
+  }
+  for (int i = 0; i < 6; ++i) {
+    if (fabsf(AT(i, i)) > 1.17549435e-38f) d[i] /= AT(i, i);
+    else d[i] = 0.0f;
+  }
+  for (int i = 5; i >= 0; --i) {
+    float s = d[i];
+    for (int r = i + 1; r < 6; ++r) s -= AT(r, i) * d[r];
+    d[i] = s;
+  }
+  for (int i = 5; i >= 0; --i)
+    if (tr[i] != i) { float t = d[i]; d[i] = d[tr[i]]; d[tr[i]] = t; }
+#undef AT
+}
+
+// meta[0] = iterations executed, meta[1] = converged, meta[2] = rows logged,
+// meta[3] = success (0 = NaN)
+__global__ __launch_bounds__(kPoThreads) void k_pose_only_mono6(
+    const float *__restrict__ X3, const float *__restrict__ uv2, int n,
+    float fx, float fy, float cx, float cy, float *T12, uint8_t *mask,
+    float thr_huber, float thr_step, float thr_cost, float thr_out, int max_it,
+    PoIter *iters, int cap, int *meta, float *debug_T12) {
+  __shared__ float red[kPoWaves][kNred];
+  __shared__ float pose[12];  // camera_to_world_optimized: R (9) then t (3)
+  __shared__ int ctl[2];      // [0] = stop flag
+  __shared__ float s_err_prev;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    // pose = reference_to_current.inverse()  (reference :52-53)
+    float R[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) R[r * 3 + c] = T12[c * 3 + r];
+    for (int k = 0; k < 9; ++k) pose[k] = R[k];
+    for (int r = 0; r < 3; ++r)
+      pose[9 + r] = -(R[r * 3 + 0] * T12[9] + R[r * 3 + 1] * T12[10] +
+                      R[r * 3 + 2] * T12[11]);
+    ctl[0] = 0;
+    s_err_prev = 1e10f;
+    meta[0] = 0;
+    meta[1] = 1;
+    meta[2] = 0;
+    meta[3] = 1;
+  }
+  __syncthreads();
+  const float inv_n = 1.0f / (float)n;
+  for (int it = 0; it < max_it; ++it) {
+    float Rl[9], tl[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rl[k] = pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tl[k] = pose[9 + k];
+    float acc[kNred];
+#pragma unroll
+    for (int k = 0; k < kNred; ++k) acc[k] = 0.0f;
+    for (int p = tid; p < n; p += kPoThreads) {
+      const float X0 = X3[3 * p], X1 = X3[3 * p + 1], X2 = X3[3 * p + 2];
+      float Lp[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        Lp[r] = (Rl[r * 3 + 0] * X0 + Rl[r * 3 + 1] * X1 + Rl[r * 3 + 2] * X2) + tl[r];
+      // reference :1350-1384
+      const float iz = 1.0f / Lp[2];
+      const float xiz = Lp[0] * iz, yiz = Lp[1] * iz;
+      const float fxxiz = fx * xiz, fyyiz = fy * yiz;
+      const float ru = (fxxiz + cx) - uv2[2 * p];
+      const float rv = (fyyiz + cy) - uv2[2 * p + 1];
+      float Ju[6], Jv[6];
+      Ju[0] = fx * iz; Ju[1] = 0.0f; Ju[2] = -fxxiz * iz; Ju[3] = -fxxiz * yiz;
+      Ju[4] = fx * (1.0f + xiz * xiz); Ju[5] = -fx * yiz;
+      Jv[0] = 0.0f; Jv[1] = fy * iz; Jv[2] = -fyyiz * iz;
+      Jv[3] = -fy * (1.0f + yiz * yiz); Jv[4] = fyyiz * xiz; Jv[5] = fy * xiz;
+      // reference :1386-1452
+      const float ars = fabsf(ru) + fabsf(rv);
+      const bool hub = ars >= thr_huber;
+      const float w = hub ? thr_huber / ars : 1.0f;
+      const float wru = hub ? w * ru : ru, wrv = hub ? w * rv : rv;
+      int k = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) {
+          float hv = 0.0f;
+          if (r != 1 && c != 1) hv += hub ? (w * Ju[r]) * Ju[c] : Ju[r] * Ju[c];
+          if (r != 0 && c != 0) hv += hub ? (w * Jv[r]) * Jv[c] : Jv[r] * Jv[c];
+          acc[k++] += hv;
+        }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[21 + c] -= wru * Ju[c] + wrv * Jv[c];
+      acc[27] += hub ? wru * ru : rv * rv;  // reference :1432,:1450 (Q9)
+      if (ars >= thr_out) mask[p] = 0;      // reference :95-98
+    }
+#pragma unroll
+    for (int k = 0; k < kNred; ++k) {
+      const float s = wave_sum_f(acc[k]);
+      if (lane == 0) red[wv][k] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float tot[kNred];
+      for (int k = 0; k < kNred; ++k) {
+        float s = 0.0f;
+        for (int w = 0; w < kPoWaves; ++w) s += red[w][k];
+        tot[k] = s;
+      }
+      float H[36], g[6];
+      int k = 0;
+      for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) {
+          H[r * 6 + c] = tot[k];
+          H[c * 6 + r] = tot[k];
+          ++k;
+        }
+      for (int r = 0; r < 6; ++r) H[r * 6 + r] *= (1.0f + 1e-5f);  // :103
+      for (int c = 0; c < 6; ++c) g[c] = tot[21 + c];
+      ldlt6_solve(H, g);  // delta_xi, reference :105
+      // se3 exponential, reference :1280-1316
+      const float v0 = g[0], v1 = g[1], v2 = g[2], w0 = g[3], w1 = g[4], w2 = g[5];
+      const float theta = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+      const float wx[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+      float wx2[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+          wx2[r * 3 + c] = wx[r * 3 + 0] * wx[0 * 3 + c] + wx[r * 3 + 1] * wx[1 * 3 + c] +
+                           wx[r * 3 + 2] * wx[2 * 3 + c];
+      float ca, cb, va, vb;
+      if (theta < 1e-7f) {
+        ca = 1.0f; cb = 0.5f; va = 0.5f; vb = 0.33333333333333333333333333f;
+      } else {
+        const float st = sinf(theta), ct = cosf(theta);
+        ca = st / theta;
+        cb = (1.0f - ct) / (theta * theta);
+        va = cb;
+        vb = (theta - st) / (theta * theta * theta);
+      }
+      float dR[9], V[9], dt[3];
+      for (int q = 0; q < 9; ++q) {
+        const float id = (q % 4 == 0) ? 1.0f : 0.0f;
+        dR[q] = id + ca * wx[q] + cb * wx2[q];
+        V[q] = id + va * wx[q] + vb * wx2[q];
+      }
+      for (int r = 0; r < 3; ++r) dt[r] = V[r * 3 + 0] * v0 + V[r * 3 + 1] * v1 + V[r * 3 + 2] * v2;
+      float Rn[9], tn[3];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          Rn[r * 3 + c] = dR[r * 3 + 0] * pose[0 * 3 + c] + dR[r * 3 + 1] * pose[1 * 3 + c] +
+                          dR[r * 3 + 2] * pose[2 * 3 + c];
+        tn[r] = dR[r * 3 + 0] * pose[9] + dR[r * 3 + 1] * pose[10] + dR[r * 3 + 2] * pose[11] + dt[r];
+      }
+      for (int q = 0; q < 9; ++q) pose[q] = Rn[q];
+      for (int q = 0; q < 3; ++q) pose[9 + q] = tn[q];
+      if (debug_T12 && it < cap) {
+        float *D = debug_T12 + 12 * it;
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) D[r * 3 + c] = Rn[c * 3 + r];
+        for (int r = 0; r < 3; ++r)
+          D[9 + r] = -(D[r * 3 + 0] * tn[0] + D[r * 3 + 1] * tn[1] + D[r * 3 + 2] * tn[2]);
+      }
+      const float err_curr = tot[27] * (inv_n * 0.5f);
+      const float delta_error = fabsf(err_curr - s_err_prev);
+      const float dn = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + w0 * w0 + w1 * w1 + w2 * w2);
+      meta[0] = it + 1;
+      if (dn < thr_step || delta_error < thr_cost) {
+        meta[1] = 1;
+        ctl[0] = 1;  // converged: no Summary row (reference :116-121)
+      } else {
+        if (it == max_it - 1) meta[1] = 0;
+        const int row = meta[2];
+        if (iters && row < cap) {
+          iters[row].cost = err_curr;
+          iters[row].cost_change = delta_error;
+          iters[row].abs_step = dn;
+        }
+        meta[2] = row + 1;
+        s_err_prev = err_curr;
+      }
+    }
+    __syncthreads();
+    if (ctl[0]) break;
+  }
+  if (tid == 0) {
+    float nrm = 0.0f;
+    for (int k = 0; k < 9; ++k) nrm += pose[k] * pose[k];
+    if (isnan(nrm)) {
+      meta[3] = 0;  // reference :159-167: do not update on NaN
+    } else {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T12[r * 3 + c] = pose[c * 3 + r];
+      for (int r = 0; r < 3; ++r)
+        T12[9 + r] = -(T12[r * 3 + 0] * pose[9] + T12[r * 3 + 1] * pose[10] +
+                       T12[r * 3 + 2] * pose[11]);
+    }
+  }
+}
+
+}  // namespace
+
+int pose_only_mono6_device(const float *dX3, const float *duv2, int n, float fx,
+                           float fy, float cx, float cy, float *dT12,
+                           uint8_t *dmask, float thr_huber, float thr_step,
+                           float thr_cost, float thr_out, int max_it,
+                           PoIter *d_iters, int cap, int *d_meta,
+                           float *d_debug, hipStream_t s) {
+  hipLaunchKernelGGL(k_pose_only_mono6, dim3(1), dim3(kPoThreads), 0, s, dX3,
+                     duv2, n, fx, fy, cx, cy, dT12, dmask, thr_huber, thr_step,
+                     thr_cost, thr_out, max_it, d_iters, cap, d_meta, d_debug);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace ba

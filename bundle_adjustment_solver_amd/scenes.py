@@ -1,0 +1,253 @@
+"""Seeded synthetic scenes for the BA hot path.
+
+* test_ba_scene        — the stereo wall scene of reference test/test_ba.cpp:
+                         53-232 (60 poses, 660 landmarks, 34 019 observations),
+                         seeded instead of std::random_device.
+* synthetic_ba_scene   — configs C2..C4: the same camera rig and trajectory
+                         law extended to N poses; every landmark is seen by a
+                         window of consecutive poses.
+* pose_only_scene      — config C5: reference
+                         test/test_compare_ceres_vs_native.cpp:20-95.
+All quantities are in USER units (metres, pixels, world->camera 4x4 poses);
+the solver facade applies the reference's 0.01 scaling.
+"""
+import numpy as np
+
+SEED_BASE = 20240600
+FX = FY = 525.0
+CX, CY = 320.0, 240.0
+WIDTH, HEIGHT = 640, 480
+BASELINE = 0.12
+
+
+def _rot(axis, ang):
+    c, s = np.cos(ang), np.sin(ang)
+    if axis == "x":
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], float)
+    if axis == "y":
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], float)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], float)
+
+
+def stereo_cameras(stereo=True):
+    """reference test/test_ba.cpp:79-98: (intr [n,4], T_cj [n,4,4])."""
+    intr = [[FX, FY, CX, CY]]
+    T = [np.eye(4)]
+    if stereo:
+        intr.append([FX, FY, CX, CY])
+        Tr = np.eye(4)
+        Tr[0, 3] = -BASELINE  # inverse of left->right translate(+0.12, 0, 0)
+        T.append(Tr)
+    return np.array(intr), np.stack(T)
+
+
+def trajectory(n_pose):
+    """World->camera poses T_wc, reference test/test_ba.cpp:132-171."""
+    base_to_cam = np.eye(4)
+    base_to_cam[:3, :3] = _rot("y", np.pi / 2) @ _rot("z", -np.pi / 2)
+    x_step = float(np.float32(0.005))
+    y_step = float(np.float32(0.2))
+    yaw_step = float(np.float32(0.005))
+    w2b = np.eye(4)
+    w2b[:3, :3] = _rot("z", -0.1)
+    w2b[:3, 3] = [-4.0, -2.5, 0.0]
+    Rz = _rot("z", yaw_step)
+    out = np.zeros((n_pose, 4, 4))
+    for k in range(n_pose):
+        w2b[:3, :3] = w2b[:3, :3] @ Rz
+        w2b[0, 3] += x_step
+        w2b[1, 3] += y_step
+        out[k] = w2b @ base_to_cam
+    return out
+
+
+def _inv(T):
+    R = T[..., :3, :3]
+    t = T[..., :3, 3]
+    out = np.zeros_like(T)
+    Rt = np.swapaxes(R, -1, -2)
+    out[..., :3, :3] = Rt
+    out[..., :3, 3] = -np.einsum("...ij,...j->...i", Rt, t)
+    out[..., 3, 3] = 1.0
+    return out
+
+
+def _wall_points():
+    """reference test/test_ba.cpp:53-77 (float loop counters)."""
+    pts = []
+    z = np.float32(1.7)
+    while z <= np.float32(5.7):
+        y = np.float32(0.0)
+        while y <= np.float32(26.0):
+            pts.append([8.5, float(y), float(z)])
+            y = np.float32(y + np.float32(0.4))
+        z = np.float32(z + np.float32(0.4))
+    return np.array(pts, float)
+
+
+def test_ba_scene(seed=SEED_BASE + 1, pixel_sigma=0.0):
+    """Scene of reference test/test_ba.cpp (config C1)."""
+    rng = np.random.default_rng(seed)
+    n_pose, n_fixed = 60, 5
+    intr, T_cj = stereo_cameras(True)
+    T_wc_true = trajectory(n_pose)
+    X_true = _wall_points()
+    n_pt = X_true.shape[0]
+    T_wc_init = T_wc_true.copy()
+    T_wc_init[n_fixed:, :3, 3] += rng.uniform(-0.1, 0.1, (n_pose - n_fixed, 3)) \
+        .astype(np.float32)
+    X_init = X_true + rng.uniform(-0.5, 0.5, (n_pt, 3)).astype(np.float32)
+    T_cw = _inv(T_wc_true)
+    cams, poses, pts, pix = [], [], [], []
+    for j in range(n_pose):
+        local = X_true @ T_cw[j, :3, :3].T + T_cw[j, :3, 3]
+        for c in range(2):
+            Xc = local @ T_cj[c, :3, :3].T + T_cj[c, :3, 3]
+            inv_z = (1.0 / Xc[:, 2]).astype(np.float32).astype(np.float64)
+            u = intr[c, 0] * Xc[:, 0] * inv_z + intr[c, 2]
+            v = intr[c, 1] * Xc[:, 1] * inv_z + intr[c, 3]
+            if pixel_sigma > 0:
+                u = u + rng.normal(0, pixel_sigma, n_pt)
+                v = v + rng.normal(0, pixel_sigma, n_pt)
+            seen = (u < WIDTH) & (u > 0) & (v < HEIGHT) & (v > 0)
+            idx = np.nonzero(seen)[0]
+            cams.append(np.full(idx.size, c, np.int32))
+            poses.append(np.full(idx.size, j, np.int32))
+            pts.append(idx.astype(np.int32))
+            pix.append(np.stack([u[idx], v[idx]], axis=1))
+    return dict(
+        intr=intr, T_cj=T_cj, T_wc_true=T_wc_true, T_wc_init=T_wc_init,
+        X_true=X_true, X_init=X_init,
+        pose_fixed=np.arange(n_pose) < n_fixed,
+        pt_fixed=np.zeros(n_pt, bool),
+        obs_cam=np.concatenate(cams), obs_pose=np.concatenate(poses),
+        obs_pt=np.concatenate(pts), obs_uv=np.concatenate(pix, axis=0))
+
+
+def synthetic_ba_scene(n_pose, n_pt, window, stereo, seed, n_fixed=5,
+                       pixel_sigma=0.0, pose_noise=0.1, point_noise=0.5):
+    """Configs C2..C4: every landmark is seen by `window`
+    consecutive poses in every camera -> n_obs = n_pt * window * n_cam."""
+    rng = np.random.default_rng(seed)
+    intr, T_cj = stereo_cameras(stereo)
+    n_cam = intr.shape[0]
+    T_wc_true = trajectory(n_pose)
+    T_cw = _inv(T_wc_true)
+    T_cam_w = np.einsum("cij,pjk->pcik", T_cj, T_cw)   # [pose, cam] world->cam
+    half = window // 2
+    X_true = np.zeros((n_pt, 3))
+    first = np.zeros(n_pt, np.int64)
+    uv_all = np.zeros((n_pt, window, n_cam, 2))
+    done = 0
+    while done < n_pt:
+        m = int((n_pt - done) * 1.3) + 64
+        center = rng.integers(half, n_pose - (window - half) + 1, m)
+        depth = rng.uniform(4.0, 12.0, m)
+        pu = rng.uniform(0, WIDTH, m)
+        pv = rng.uniform(0, HEIGHT, m)
+        Xc = np.stack([(pu - CX) / FX * depth, (pv - CY) / FY * depth, depth], 1)
+        Tw = T_wc_true[center]
+        Xw = np.einsum("mij,mj->mi", Tw[:, :3, :3], Xc) + Tw[:, :3, 3]
+        f0 = center - half
+        ok = np.ones(m, bool)
+        uvw = np.zeros((m, window, n_cam, 2))
+        for w in range(window):
+            T = T_cam_w[f0 + w]                      # [m, cam, 4, 4]
+            Xl = np.einsum("mcij,mj->mci", T[:, :, :3, :3], Xw) + T[:, :, :3, 3]
+            z = Xl[..., 2]
+            u = intr[None, :, 0] * Xl[..., 0] / z + intr[None, :, 2]
+            v = intr[None, :, 1] * Xl[..., 1] / z + intr[None, :, 3]
+            good = (z > 0) & (u > 0) & (u < WIDTH) & (v > 0) & (v < HEIGHT)
+            ok &= good.all(axis=1)
+            uvw[:, w, :, 0] = u
+            uvw[:, w, :, 1] = v
+        idx = np.nonzero(ok)[0][:n_pt - done]
+        k = idx.size
+        X_true[done:done + k] = Xw[idx]
+        first[done:done + k] = f0[idx]
+        uv_all[done:done + k] = uvw[idx]
+        done += k
+    # observation list, insertion order pose-major, left then right, landmark
+    lm = np.repeat(np.arange(n_pt), window * n_cam)
+    wi = np.tile(np.repeat(np.arange(window), n_cam), n_pt)
+    ci = np.tile(np.arange(n_cam), n_pt * window)
+    pose = first[lm] + wi
+    uv = uv_all.reshape(-1, 2)
+    if pixel_sigma > 0:
+        uv = uv + rng.normal(0, pixel_sigma, uv.shape)
+    order = np.lexsort((lm, ci, pose))
+    T_wc_init = T_wc_true.copy()
+    T_wc_init[n_fixed:, :3, 3] += rng.uniform(-pose_noise, pose_noise,
+                                              (n_pose - n_fixed, 3))
+    X_init = X_true + rng.uniform(-point_noise, point_noise, (n_pt, 3))
+    return dict(
+        intr=intr, T_cj=T_cj, T_wc_true=T_wc_true, T_wc_init=T_wc_init,
+        X_true=X_true, X_init=X_init,
+        pose_fixed=np.arange(n_pose) < n_fixed,
+        pt_fixed=np.zeros(n_pt, bool),
+        obs_cam=ci[order].astype(np.int32),
+        obs_pose=pose[order].astype(np.int32),
+        obs_pt=lm[order].astype(np.int32), obs_uv=uv[order])
+
+
+# name -> (n_pose, n_pt, window, stereo, seed)   (BASELINE.json configs)
+CONFIGS = {
+    "C2": (200, 50_000, 10, False, SEED_BASE + 2),
+    "C3": (500, 200_000, 5, True, SEED_BASE + 3),
+    "C4": (1000, 500_000, 5, True, SEED_BASE + 4),
+}
+
+
+def config_scene(name, scale=1.0):
+    """Scene of a BASELINE.json config; scale<1 shrinks poses and landmarks
+    proportionally (parity-test sizes)."""
+    if name == "C1":
+        return test_ba_scene()
+    n_pose, n_pt, window, stereo, seed = CONFIGS[name]
+    n_pose = max(window + 6, int(round(n_pose * scale)))
+    n_pt = max(16, int(round(n_pt * scale)))
+    return synthetic_ba_scene(n_pose, n_pt, window, stereo, seed)
+
+
+def scaled_problem(scene):
+    """Apply the facade's host preprocessing (reference
+    core/full_bundle_adjustment_solver.cpp:72-117,155-180): 0.01 scaling,
+    T_jw = pose^-1; returns the C-ABI level arrays."""
+    s = 0.01
+    intr = scene["intr"] * s
+    T_cj = scene["T_cj"].copy()
+    T_cj[:, :3, 3] *= s
+    T_jw = _inv(scene["T_wc_init"])
+    T_jw[:, :3, 3] *= s
+    to12 = lambda T: np.concatenate(
+        [T[:, :3, :3].reshape(-1, 9), T[:, :3, 3]], axis=1)
+    return dict(
+        cam_intr=np.ascontiguousarray(intr), cam_T=to12(T_cj),
+        pose_T=to12(T_jw), pose_fixed=scene["pose_fixed"].astype(np.uint8),
+        pt_X=np.ascontiguousarray(scene["X_init"] * s),
+        pt_fixed=scene["pt_fixed"].astype(np.uint8),
+        obs_cam=scene["obs_cam"].astype(np.int32),
+        obs_pose=scene["obs_pose"].astype(np.int32),
+        obs_pt=scene["obs_pt"].astype(np.int32),
+        obs_uv=np.ascontiguousarray(scene["obs_uv"] * s))
+
+
+def pose_only_scene(n=10_000, seed=SEED_BASE + 5, pixel_sigma=0.0):
+    """Config C5, reference test/test_compare_ceres_vs_native.cpp:20-95."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 338.0
+    cx, cy = 320.0, 240.0
+    T_true = np.eye(4, dtype=np.float32)
+    T_true[:3, :3] = _rot("y", -0.5).astype(np.float32)
+    T_true[:3, 3] = [0.2, 0.3, -1.9]
+    X = np.stack([rng.uniform(-1.7, 1.7, n), rng.uniform(-1.3, 1.3, n),
+                  rng.uniform(0, 5.0, n) + 1.2], axis=1).astype(np.float32)
+    Ti = _inv(T_true.astype(np.float64)).astype(np.float32)
+    L = X @ Ti[:3, :3].T + Ti[:3, 3]
+    inv_z = (np.float32(1.0) / L[:, 2]).astype(np.float32)
+    uv = np.stack([fx * L[:, 0] * inv_z + cx, fy * L[:, 1] * inv_z + cy],
+                  axis=1).astype(np.float32)
+    if pixel_sigma > 0:
+        uv = (uv + rng.normal(0, pixel_sigma, uv.shape)).astype(np.float32)
+    return dict(X=X, uv=uv, fx=fx, fy=fy, cx=cx, cy=cy, T_true=T_true,
+                T_init=np.eye(4, dtype=np.float32))

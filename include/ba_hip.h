@@ -1,0 +1,195 @@
+/*
+ * ba_hip.h — C ABI of the MI355X (gfx950) bundle-adjustment hot path.
+ *
+ * The reference has no FFI / plugin layer: its boundary is the C++ class
+ * FullBundleAdjustmentSolver (reference core/full_bundle_adjustment_solver.h:
+ * 127-146) whose Solve() (reference core/full_bundle_adjustment_solver.cpp:
+ * 630-1044) is the hot path.  This header is the thin C ABI a replacement
+ * facade binds: plain pointers and sizes, an opaque handle,
+ * no C++ or torch types.  Every entry point names the reference lines it
+ * replaces.  Conventions:
+ *   - return 0 = OK, negative = error (message via ba_last_error()); no C++
+ *     exception crosses the ABI;
+ *   - caller-owned HOST arrays are copied at set_* time;
+ *   - all values are in the solver's SCALED units: the facade applies the
+ *     reference's 0.01 scaling (reference :38, :74-79, :97, :113, :176),
+ *     inverts user poses into T_jw (reference :96) and maps pointers to
+ *     indices before calling in;
+ *   - rigid transforms are 12 doubles: row-major 3x3 rotation, then t;
+ *   - one handle per host thread; a handle owns one GPU.
+ */
+#ifndef BA_HIP_H_
+#define BA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ba_handle ba_handle;
+
+/* Mirrors Options (reference core/solver_option_and_summary.h:47-71); the
+ * fields are float there and are promoted to double inside the LM update
+ * (reference core/full_bundle_adjustment_solver.cpp:949,953). */
+typedef struct {
+  float threshold_step_size;         /* convergence_handle  */
+  float threshold_cost_change;       /* convergence_handle  */
+  float threshold_huber_loss;        /* outlier_handle      */
+  float threshold_outlier_rejection; /* unused by full BA   */
+  int max_num_iterations;            /* iteration_handle    */
+  float initial_lambda;              /* trust_region_handle */
+  float decrease_ratio_lambda;
+  float increase_ratio_lambda;
+} ba_options;
+
+/* One row per LM iteration: OptimizationInfo (reference
+ * core/solver_option_and_summary.h:37-46) + the trust-region internals. */
+typedef struct {
+  double cost;
+  double cost_change;
+  double average_reprojection_error;
+  double abs_gradient;
+  double abs_step;
+  double damping_term;
+  double iter_time_ms;
+  int iteration_status; /* 0 UPDATE, 1 UPDATE_TRUST_MORE, 2 SKIPPED */
+  int pad_;
+  double rho;
+  double model_change;
+  double trial_cost;
+} ba_iter_info;
+
+/* ---- lifetime --------------------------------------------------------- */
+/* replaces the constructor / destructor / Reset (reference :6-70) */
+int ba_create(ba_handle **out, int device_id);
+void ba_destroy(ba_handle *h);
+const char *ba_last_error(void);
+/* Run all kernels of this handle on the given hipStream_t (NULL = the
+ * handle's own stream). */
+int ba_set_stream(ba_handle *h, void *hip_stream);
+
+/* ---- problem construction (host arrays, copied) ------------------------ */
+/* AddCamera, reference :72-85.  intr4 = fx,fy,cx,cy ; T_cj12 = body->camera */
+int ba_set_cameras(ba_handle *h, int n_cam, const double *intr4,
+                   const double *T_cj12);
+/* AddPose + MakePoseFixed, reference :87-101, :119-134.  T_jw = pose^-1 */
+int ba_set_poses(ba_handle *h, int n_pose, const double *T_jw12,
+                 const uint8_t *fixed);
+/* AddPoint + MakePointFixed, reference :103-117, :136-153 */
+int ba_set_points(ba_handle *h, int n_pt, const double *X3,
+                  const uint8_t *fixed);
+/* AddObservation, reference :155-180.  Insertion order is preserved: it
+ * decides which camera's cross term B_ji survives (reference :826). */
+int ba_set_observations(ba_handle *h, int64_t n_obs, const int32_t *cam,
+                        const int32_t *pose, const int32_t *point,
+                        const double *uv2);
+/* Landmark-range sharding for multi-GPU (new).  Call before
+ * ba_finalize with the same full problem on every rank. */
+int ba_set_shard(ba_handle *h, int rank, int world);
+/* FinalizeParameters + SetProblemSize + connectivity, reference :182-206,
+ * :243-308, :668-700: index assignment, block-sparse structure, upload. */
+int ba_finalize(ba_handle *h);
+
+/* Host-only helper (no GPU needed): owner rank of every point under the
+ * sharding rule used by ba_finalize. */
+int ba_partition_points(int n_pose, const uint8_t *pose_fixed, int n_pt,
+                        const uint8_t *pt_fixed, int64_t n_obs,
+                        const int32_t *obs_pose, const int32_t *obs_pt,
+                        int world, int32_t *owner_out);
+
+/* ---- multi-GPU exchange hook ------------------------------------------- */
+/* The caller owns the collective (RCCL through torch.distributed, or
+ * anything else).  `which`: 0 = reduced camera system S||rhs, 1 = LM scalars.
+ * The hook must sum-all-reduce n doubles at dev_ptr in place, ordered on
+ * hip_stream. */
+typedef int (*ba_allreduce_fn)(void *user, int which, void *dev_ptr,
+                               int64_t n_doubles, void *hip_stream);
+int ba_set_allreduce(ba_handle *h, ba_allreduce_fn fn, void *user);
+/* Size (in doubles) of exchange buffer `which`, valid after ba_finalize. */
+int64_t ba_reduce_buffer_size(ba_handle *h, int which);
+/* Use caller-allocated DEVICE memory for exchange buffer `which` (so that a
+ * framework tensor can alias it).  Call after ba_finalize. */
+int ba_bind_reduce_buffer(ba_handle *h, int which, void *dev_ptr,
+                          int64_t n_doubles);
+
+/* ---- the LM loop ------------------------------------------------------- */
+/* Solve, reference :630-1044 (iteration loop :705-1008).  Runs until
+ * convergence or max_num_iterations; fills up to `cap` rows. */
+int ba_solve(ba_handle *h, const ba_options *opt, ba_iter_info *out, int cap,
+             int *n_iter, int *converged);
+/* The same loop in three asynchronous pieces (bench / graph replay):
+ * begin = lambda0 + initial cost (reference :707-708); iterate = enqueue n
+ * LM iterations without host synchronisation (iterations after convergence
+ * are device-side no-ops); sync = wait and read the iteration log. */
+int ba_lm_begin(ba_handle *h, const ba_options *opt);
+int ba_lm_iterate(ba_handle *h, int n);
+int ba_lm_sync(ba_handle *h, ba_iter_info *out, int cap, int *n_iter,
+               int *converged);
+
+/* ---- stage entry points (parity tests, per-stage timing) --------------- */
+int ba_stage_cost(ba_handle *h, double *cost);            /* :381-433 */
+int ba_stage_linearize(ba_handle *h, double lambda,
+                       double huber);                     /* :716-856 */
+int ba_stage_schur(ba_handle *h);                         /* :858-902 */
+int ba_stage_solve_reduced(ba_handle *h);                 /* :905-908 */
+int ba_stage_backsub_update(ba_handle *h);  /* :910-926, :435-455, :960-963 */
+/* after ba_stage_backsub_update: trial cost, model change, step norms */
+int ba_stage_scalars(ba_handle *h, double *trial_cost, double *model_change,
+                     double *pose_step_sum, double *point_step_sum);
+/* accept (1) or reject (0) the trial parameters, reference :939-945 */
+int ba_stage_commit(ba_handle *h, int accept);
+
+/* Accumulated device time per stage in ms since the last reset (hipEvents;
+ * enabled by ba_enable_stage_timing): [0] build (linearize), [1] schur,
+ * [2] reduced solve, [3] backsub+update, [4] cost, [5] control,
+ * [6] exchange (all-reduce hook), [7] reserved. */
+int ba_enable_stage_timing(ba_handle *h, int on);
+int ba_get_stage_ms(ba_handle *h, double out8[8], int reset);
+
+/* ---- readers (user index order; opt order = input order of non-fixed) -- */
+int ba_num_opt_poses(ba_handle *h);
+int ba_num_opt_points(ba_handle *h); /* local (owned) optimisable points */
+int64_t ba_num_pairs(ba_handle *h);
+int64_t ba_num_schur_blocks(ba_handle *h);
+int64_t ba_num_schur_triples(ba_handle *h);
+/* current parameters, write-back source (reference :1011-1022) */
+int ba_get_poses(ba_handle *h, double *T_jw12 /* n_pose*12 */);
+/* points not owned by this shard are left untouched; owned_mask may be NULL */
+int ba_get_points(ba_handle *h, double *X3 /* n_pt*3 */, uint8_t *owned_mask);
+/* damped A_j (6x6 full) and a_j, per optimised pose */
+int ba_get_A(ba_handle *h, double *A36, double *a6);
+/* damped C_i (3x3 full), b_i; Cinv_i, Cinv_i b_i.  Indexed by GLOBAL opt
+ * point index; entries of points owned by other shards are left untouched */
+int ba_get_C(ba_handle *h, double *C9, double *b3);
+int ba_get_Cinv(ba_handle *h, double *Cinv9, double *Cinvb3);
+/* pairs (global i_opt, j_opt) in internal order with W = B_ji (6x3) */
+int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18);
+/* reduced camera system, (6N)^2 row-major, and rhs, in opt-pose order */
+int ba_get_S(ba_handle *h, double *S, double *rhs);
+int ba_get_xy(ba_handle *h, double *x6, double *y3);
+
+/* ---- dense SPD solve alone (tests / micro-bench of the MFMA kernel) ---- */
+/* Solves A x = b for symmetric positive (semi-)definite A (n x n row-major
+ * host arrays) with the blocked fp64-MFMA Cholesky used for the reduced
+ * camera system.  `ms` (optional) receives the device time of the solve. */
+int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
+                       double *x, double *ms);
+
+/* ---- pose-only, monocular 6-DoF (fp32) --------------------------------- */
+/* Solve_Monocular_6Dof, reference
+ * core/pose_only_bundle_adjustment_solver.cpp:8-170.  T12 in/out is
+ * reference_to_current_pose; mask is n bytes in/out (sticky false). */
+typedef struct {
+  float cost, cost_change, abs_step;
+} ba_po_iter;
+int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
+                       float fx, float fy, float cx, float cy, float *T12,
+                       uint8_t *mask, const ba_options *opt, ba_po_iter *iters,
+                       int cap, int *n_iter, int *converged,
+                       float *debug_T12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_HIP_H_ */

@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) GPU")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure both shared objects exist (built in-tree, never JIT)."""
+    import __graft_entry__ as g
+    g.build(only_if_missing=True)
+    return True

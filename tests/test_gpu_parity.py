@@ -1,0 +1,266 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle
+on the same seeded inputs, stage by stage and over the whole LM loop.
+
+Tolerances (fp64): the GPU and the oracle differ only in floating-point
+summation order, so per-block results must agree to ~1e-11 relative; the
+north-star acceptance bound for final poses / points is 1e-4 relative.
+"""
+import numpy as np
+import pytest
+
+from bundle_adjustment_solver_amd import scenes
+from bundle_adjustment_solver_amd._lib import BaOptions
+from bundle_adjustment_solver_amd.solver import BaProblem
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL_BLOCK = 1e-10     # per-block relative tolerance (max-norm of the block)
+RTOL_FINAL = 1e-4      # north_star: final poses / points within 1e-4 rel
+
+
+def make_gpu(pr, rank=0, world=1):
+    p = BaProblem(0)
+    p.set_cameras(pr["cam_intr"], pr["cam_T"])
+    p.set_poses(pr["pose_T"], pr["pose_fixed"])
+    p.set_points(pr["pt_X"], pr["pt_fixed"])
+    p.set_observations(pr["obs_cam"], pr["obs_pose"], pr["obs_pt"],
+                       pr["obs_uv"])
+    if world > 1:
+        p.set_shard(rank, world)
+    p.finalize()
+    return p
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    den = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() / den
+
+
+def blockwise_relerr(a, b):
+    """max over leading index of |a-b|_max / |b|_max (blocks with b == 0 must
+    be exactly 0 in a)."""
+    a = np.asarray(a).reshape(a.shape[0], -1)
+    b = np.asarray(b).reshape(b.shape[0], -1)
+    den = np.abs(b).max(axis=1)
+    num = np.abs(a - b).max(axis=1)
+    z = den == 0
+    assert (num[z] == 0).all()
+    return (num[~z] / den[~z]).max() if (~z).any() else 0.0
+
+
+def small_scene(kind):
+    if kind == "c1":
+        return scenes.test_ba_scene()
+    if kind == "mono":
+        return scenes.synthetic_ba_scene(24, 1500, 10, False, seed=11)
+    if kind == "stereo":
+        return scenes.synthetic_ba_scene(40, 3000, 5, True, seed=12)
+    raise ValueError(kind)
+
+
+@pytest.fixture(scope="module", params=["c1", "mono", "stereo"])
+def pair(request, built):
+    sc = small_scene(request.param)
+    pr = scenes.scaled_problem(sc)
+    return pr, make_gpu(pr), O.Oracle(pr)
+
+
+def test_cost(pair):
+    pr, g, o = pair
+    assert relerr(g.stage_cost(), o.cost()) < 1e-12
+
+
+def test_linearize_blocks(pair):
+    pr, g, o = pair
+    lam, hub = 3.7, 1.0
+    o.linearize(hub)
+    o.damp_invert(lam)
+    g.stage_linearize(lam, hub)
+    A, a = g.get_A()
+    oA, oa = o.get_A()
+    assert blockwise_relerr(A, oA) < RTOL_BLOCK
+    assert blockwise_relerr(a, oa) < RTOL_BLOCK
+    Cm, b = g.get_C()
+    oC, ob = o.get_C()
+    assert blockwise_relerr(Cm, oC) < RTOL_BLOCK
+    assert blockwise_relerr(b, ob) < RTOL_BLOCK
+    Ci, cb = g.get_Cinv()
+    oCi, ocb = o.get_Cinv()
+    # inverse of a 3x3 block: relative to the block's own scale, conditioning
+    # of C_i enters (well below 1e6 here)
+    assert blockwise_relerr(Ci, oCi) < 1e-7
+    assert blockwise_relerr(cb, ocb) < 1e-7
+    pi, pj, W = g.get_pairs()
+    opi, opj, oW = o.get_pairs()
+    assert len(pi) == len(opi)
+    key = np.lexsort((pj, pi))
+    okey = np.lexsort((opj, opi))
+    assert (pi[key] == opi[okey]).all() and (pj[key] == opj[okey]).all()
+    assert blockwise_relerr(W[key], oW[okey]) < RTOL_BLOCK
+
+
+def test_schur_solve_backsub(pair):
+    pr, g, o = pair
+    lam, hub = 0.5, 1.0
+    o.linearize(hub)
+    o.damp_invert(lam)
+    o.schur()
+    g.stage_linearize(lam, hub)
+    g.stage_schur()
+    S, rhs = g.get_S()
+    oS, orhs = o.get_S()
+    assert relerr(S, oS) < 1e-9
+    assert relerr(rhs, orhs) < 1e-9
+    o.solve_reduced()
+    o.backsub()
+    g.stage_solve_reduced()
+    g.stage_backsub_update()
+    x, y = g.get_xy()
+    ox, oy = o.get_xy()
+    # x solves S x = rhs: compare through the residual and directly
+    n6 = S.shape[0]
+    res = np.abs(oS @ x.reshape(-1) - orhs).max() / np.abs(orhs).max()
+    assert res < 1e-8
+    assert relerr(x, ox) < 1e-6
+    assert relerr(y, oy) < 1e-6
+    # trial parameters, model change, step norms
+    o.backup()
+    o.update()
+    ocost = o.cost()
+    omodel = o.model_change()
+    osp, osq = o.step_norms()
+    cost, model, sp, sq = g.stage_scalars()
+    assert relerr(cost, ocost) < 1e-9
+    assert relerr(model, omodel) < 1e-6
+    assert relerr(sp, osp) < 1e-6 and relerr(sq, osq) < 1e-6
+    g.stage_commit(False)
+    o.revert()
+    assert relerr(g.stage_cost(), o.cost()) < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["c1", "mono", "stereo"])
+def test_lm_trajectory(kind, built):
+    """Whole LM loop: same accept/reject sequence, same lambda sequence,
+    costs to 1e-8, final parameters far inside the 1e-4 acceptance bound."""
+    sc = small_scene(kind)
+    pr = scenes.scaled_problem(sc)
+    n_it = 25
+    g = make_gpu(pr)
+    o = O.Oracle(pr)
+    rows, conv = g.solve(O.make_options(max_iter=n_it, thr_step=1e-7,
+                                        thr_cost=1e-7, cls=BaOptions))
+    orows, oconv = o.solve(O.make_options(max_iter=n_it, thr_step=1e-7,
+                                          thr_cost=1e-7))
+    assert len(rows) == len(orows) and conv == oconv
+    for k, (a, b) in enumerate(zip(rows, orows)):
+        assert a.iteration_status == b.iteration_status, k
+        assert relerr(a.damping_term, b.damping_term) < 1e-12, k
+        assert relerr(a.trial_cost, b.trial_cost) < 1e-7, k
+        assert relerr(a.cost, b.cost) < 1e-7, k
+        assert relerr(a.abs_step, b.abs_step) < 1e-5, k
+    P, oP = g.get_poses(), o.get_poses()
+    X, oX = g.get_points()[0], o.get_points()
+    assert relerr(P, oP) < RTOL_FINAL * 1e-2
+    assert relerr(X, oX) < RTOL_FINAL * 1e-2
+
+
+def test_converges_to_truth(built):
+    """Noise-free scene: the HIP solver must reach the ground truth."""
+    sc = scenes.synthetic_ba_scene(20, 800, 5, True, seed=3)
+    pr = scenes.scaled_problem(sc)
+    g = make_gpu(pr)
+    rows, conv = g.solve(O.make_options(max_iter=60, thr_step=1e-9,
+                                        thr_cost=1e-9, cls=BaOptions))
+    X = g.get_points()[0] / 0.01
+    err = np.linalg.norm(X - sc["X_true"], axis=1)
+    assert rows[-1].cost < 1e-3 * rows[0].cost
+    assert np.median(err) < 1e-3   # metres
+
+
+def test_edge_cases(built):
+    """Never-observed landmark (C_i = 0 -> Cinv = 0), fixed
+    landmark, landmark seen by fixed poses only, pose without observations."""
+    sc = scenes.synthetic_ba_scene(12, 60, 5, False, seed=5)
+    # landmark 0: unobserved; landmark 1: fixed; pose 11: no observations
+    keep = (sc["obs_pt"] != 0) & (sc["obs_pose"] != 11)
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        sc[k] = sc[k][keep]
+    sc["pt_fixed"][1] = True
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    lam = 2.0
+    o.linearize(1.0); o.damp_invert(lam); o.schur()
+    o.solve_reduced(); o.backsub()
+    g.stage_linearize(lam, 1.0); g.stage_schur()
+    S, rhs = g.get_S()
+    oS, orhs = o.get_S()
+    assert relerr(S, oS) < 1e-9
+    g.stage_solve_reduced(); g.stage_backsub_update()
+    Ci, _ = g.get_Cinv()
+    assert (Ci[0] == 0).all()            # pseudo-inverse, not NaN
+    x, y = g.get_xy()
+    ox, oy = o.get_xy()
+    assert np.isfinite(x).all() and np.isfinite(y).all()
+    assert relerr(x, ox) < 1e-6 and relerr(y, oy) < 1e-6
+    jlast = o.N - 1                      # pose 11 -> zero row/col -> x = 0
+    assert (x[jlast] == 0).all() and np.abs(ox[jlast]).max() == 0
+    rows, _ = g.solve(O.make_options(max_iter=10, thr_step=0, thr_cost=0,
+                                     cls=BaOptions))
+    orows, _ = o.solve(O.make_options(max_iter=10, thr_step=0, thr_cost=0))
+    for a, b in zip(rows, orows):
+        assert a.iteration_status == b.iteration_status
+        assert relerr(a.trial_cost, b.trial_cost) < 1e-7
+    assert relerr(g.get_points()[0], o.get_points()) < 1e-6
+
+
+def test_last_writer_quirk(built):
+    """Stereo: B_ji keeps only the LAST-inserted camera's cross term
+    (reference :826): reversing the insertion order of the two
+    cameras changes W but neither A, C, a nor b."""
+    sc = scenes.synthetic_ba_scene(10, 80, 5, True, seed=9)
+    pr = scenes.scaled_problem(sc)
+    g1 = make_gpu(pr)
+    g1.stage_linearize(1.0, 1.0)
+    pr2 = dict(pr)
+    order = np.lexsort((pr["obs_pt"], -pr["obs_cam"], pr["obs_pose"]))
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        pr2[k] = np.ascontiguousarray(pr[k][order])
+    g2, o2 = make_gpu(pr2), O.Oracle(pr2)
+    g2.stage_linearize(1.0, 1.0)
+    o2.linearize(1.0); o2.damp_invert(1.0)
+    A1, a1 = g1.get_A(); A2, a2 = g2.get_A()
+    assert relerr(A1, A2) < 1e-12 and relerr(a1, a2) < 1e-12
+    _, _, W1 = g1.get_pairs(); pi2, pj2, W2 = g2.get_pairs()
+    assert relerr(W1, W2) > 1e-3          # different camera survived
+    opi, opj, oW = o2.get_pairs()
+    k1, k2 = np.lexsort((pj2, pi2)), np.lexsort((opj, opi))
+    assert blockwise_relerr(W2[k1], oW[k2]) < RTOL_BLOCK
+
+
+def test_dense_spd_solve(built):
+    """The MFMA Cholesky alone, incl. non-multiple-of-64 sizes."""
+    rng = np.random.default_rng(0)
+    g = BaProblem(0)
+    for n in (6, 64, 100, 330, 1000):
+        Q = rng.standard_normal((n, n))
+        A = Q @ Q.T + n * np.eye(n)
+        b = rng.standard_normal(n)
+        x, ms = g.dense_spd_solve(A, b)
+        ref = np.linalg.solve(A, b)
+        assert relerr(x, ref) < 1e-10, n
+
+
+def test_reproducible_bits(built):
+    """No floating-point atomics: two runs give bit-identical results."""
+    sc = small_scene("stereo")
+    pr = scenes.scaled_problem(sc)
+    outs = []
+    for _ in range(2):
+        g = make_gpu(pr)
+        g.solve(O.make_options(max_iter=6, thr_step=0, thr_cost=0,
+                               cls=BaOptions))
+        outs.append((g.get_poses().copy(), g.get_points()[0].copy()))
+    assert (outs[0][0] == outs[1][0]).all()
+    assert (outs[0][1] == outs[1][1]).all()
