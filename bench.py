@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py — LM iterations/s of the full-BA hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--config C4]
+
+A "step" is one LM iteration (linearise -> Schur -> dense reduced solve ->
+back-substitution/update -> trial cost -> trust-region control; reference
+core/full_bundle_adjustment_solver.cpp:709-1007) of BASELINE.json's flagship
+workload C4 (stereo, 1 000 poses / 500 000 landmarks / 5 000 000
+observations, synthetic, seeded).  N > 1: one process per GPU (torchrun),
+landmarks sharded across ranks, one RCCL all-reduce of the reduced camera
+system per iteration (strong scaling: the problem is fixed).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6  # public MI355X datasheet (not in local guides)
+
+WORKLOADS = {
+    "C1": "C1 test_ba.cpp stereo scene: 60 poses / 660 landmarks / 34019 obs",
+    "C2": "C2 mono 6-DoF: 200 poses / 50k landmarks / 500k obs",
+    "C3": "C3 stereo 6-DoF: 500 poses / 200k landmarks / 2M obs",
+    "C4": "C4 stereo 6-DoF: 1000 poses / 500k landmarks / 5M obs",
+}
+
+
+def algorithmic_bytes(O, P, M, N):
+    """bytes per LM iteration by stage (fp64)."""
+    n6 = 6 * N
+    build = 32 * O + 144 * P + 96 * M + 312 * N
+    schur = 144 * P + 168 * M + 264 * N + 8 * n6 * n6
+    solve = 16 * n6 * n6 + 144 * P + 192 * M + 144 * N
+    control = 32 * O + 120 * M + 384 * N
+    return dict(build=build, schur=schur, solve=solve, control=control,
+                total=build + schur + solve + control)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0,
+                    help="shrink the config (debug only; result is then "
+                         "labelled as such)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    ge.build(only_if_missing=True)
+    from bundle_adjustment_solver_amd import scenes
+    from bundle_adjustment_solver_amd._lib import BaOptions
+    from bundle_adjustment_solver_amd.solver import BaProblem
+    from oracle import oracle_py as O
+
+    t_gen = time.time()
+    sc = scenes.config_scene(args.config, args.scale)
+    pr = scenes.scaled_problem(sc)
+    t_gen = time.time() - t_gen
+
+    p = BaProblem(local_rank)
+    p.set_cameras(pr["cam_intr"], pr["cam_T"])
+    p.set_poses(pr["pose_T"], pr["pose_fixed"])
+    p.set_points(pr["pt_X"], pr["pt_fixed"])
+    p.set_observations(pr["obs_cam"], pr["obs_pose"], pr["obs_pt"],
+                       pr["obs_uv"])
+    keep = []
+    if world > 1:
+        p.set_shard(rank, world)
+        p.set_stream(torch.cuda.current_stream().cuda_stream)
+    t_fin = time.time()
+    p.finalize()
+    t_fin = time.time() - t_fin
+    if world > 1:
+        bufs = []
+        for which in (0, 1):
+            n = p.reduce_buffer_size(which)
+            t = torch.zeros(n, dtype=torch.float64, device="cuda")
+            p.bind_reduce_buffer(which, t.data_ptr(), n)
+            bufs.append(t)
+        keep.append(bufs)
+
+        def hook(which, ptr, n, stream):
+            dist.all_reduce(bufs[which])
+            return 0
+        p.set_allreduce(hook)
+
+    n_obs = int(pr["obs_cam"].shape[0])
+    N = p.N
+    M_glob = int((pr["pt_fixed"] == 0).sum())
+    # the LM loop must not stop inside the timed region: thresholds < 0
+    opt = O.make_options(max_iter=args.warmup + args.steps + 1, thr_step=-1.0,
+                         thr_cost=-1.0, cls=BaOptions)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    p.lm_begin(opt)
+    p.lm_iterate(args.warmup)
+    p.lm_sync()
+    sync_all()
+    t0 = time.perf_counter()
+    p.lm_iterate(args.steps)
+    p.lm_sync()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    rows, n_done, conv, done = p.lm_sync(cap=args.warmup + args.steps + 1)
+    assert n_done == args.warmup + args.steps, (n_done, args)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    result = {
+        "metric": "lm_iterations_per_sec",
+        "value": args.steps / elapsed,
+        "unit": "it/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": WORKLOADS[args.config] +
+            ("" if args.scale == 1.0 else " (scaled x%g, debug)" % args.scale),
+            "n_opt_poses": N, "n_opt_landmarks": M_glob,
+            "n_observations": n_obs,
+            "parallelism": "landmark-shard x%d + all-reduce(S|rhs)" % world
+            if world > 1 else "single GPU",
+        },
+        "obs_iterations_per_sec": n_obs * args.steps / elapsed,
+        "final_cost": rows[-1].cost if rows else None,
+        "host_prep_s": {"scene_gen": t_gen, "finalize_upload": t_fin},
+    }
+
+    # ---- per-stage device times + roofline (separate instrumented pass on
+    # the same problem, so that the headline region stays un-instrumented) ---
+    if not args.no_roofline:
+        p.enable_stage_timing(True)
+        p.get_stage_ms(reset=True)
+        n_prof = min(5, max(1, args.steps))
+        opt2 = O.make_options(max_iter=n_prof, thr_step=-1.0, thr_cost=-1.0,
+                              cls=BaOptions)
+        p.lm_begin(opt2)
+        p.lm_iterate(n_prof)
+        p.lm_sync()
+        st = p.get_stage_ms(reset=True) / n_prof
+        p.enable_stage_timing(False)
+        names = ["build", "schur", "solve", "backsub_update", "cost",
+                 "control", "exchange"]
+        result["stage_ms"] = {k: float(v) for k, v in zip(names, st)}
+        if world == 1:
+            P = int(p.P)
+            ab = algorithmic_bytes(n_obs, P, M_glob, N)
+            n6 = 6 * N
+            flops = n6 ** 3 / 3.0 + 4.0 * n6 * n6
+            st_d = dict(zip(names, st))
+            hbm_ms = st_d["build"] + st_d["schur"] + st_d["backsub_update"] + \
+                st_d["cost"]
+            hbm_bytes = ab["total"] - 16 * n6 * n6
+            result["roofline_hbm_stages"] = {
+                "bound": "hbm", "achieved": hbm_bytes / (hbm_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": hbm_bytes / (hbm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None,
+                "note": "all HBM-bound stages together (build+schur+backsub+"
+                        "cost), algorithmic bytes of SURVEY.md §8(d) minus "
+                        "the dense factor's 16*(6N)^2"}
+            if st_d["solve"] >= hbm_ms:
+                ach = flops / (st_d["solve"] * 1e-3) / 1e12
+                result["roofline"] = {
+                    "bound": "mfma", "achieved": ach,
+                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "kernel": "dense reduced solve (blocked Cholesky: "
+                              "k_chol_diag/trsm/syrk/back), (6N)^3/3 + 4(6N)^2"
+                              " flop per LM iteration"}
+            else:
+                result["roofline"] = dict(result["roofline_hbm_stages"])
+
+    # ---- CPU baseline: the oracle on the box's host cores, 1 thread -------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        o = O.Oracle(pr)
+        t = time.perf_counter()
+        orows, _ = o.solve(O.make_options(max_iter=1, thr_step=-1.0,
+                                          thr_cost=-1.0))
+        dt = time.perf_counter() - t
+        result["cpu_baseline"] = {
+            "value": 1.0 / dt, "unit": "it/s", "cores": 1, "kind": "port",
+            "sample": "1 LM iteration of the same %s problem (block-sparse "
+                      "oracle, reference's unblocked pivoted LDLT for the "
+                      "dense solve), %.1f s; stage ms build/schur/solve/"
+                      "control = %s" % (args.config, dt, ", ".join(
+                          "%.0f" % v for v in o.stage_ms())),
+            "host_cpus": os.cpu_count(),
+        }
+        # same first iteration on GPU and CPU: parity spot check
+        if rows:
+            result["cpu_baseline"]["first_iter_trial_cost_rel_diff"] = abs(
+                rows[0].trial_cost - orows[0].trial_cost) / abs(
+                    orows[0].trial_cost)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
