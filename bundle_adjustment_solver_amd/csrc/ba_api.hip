@@ -409,7 +409,7 @@ int ba_finalize(ba_handle *h) {
   h->xbuf_n[1] = 4;
   if (h->dalloc(&d.L, (size_t)h->xbuf_n[0])) return -1;
   const size_t ncb = (size_t)d.npad / ba::kDenseNb;
-  if (h->dalloc(&d.Ldiag, ncb * ba::kDenseNb * ba::kDenseNb + d.npad)) return -1;
+  if (h->dalloc(&d.Ldiag, ncb * ba::kDenseWsPerBlock)) return -1;
 
   std::memset(&h->hc, 0, sizeof(h->hc));
   h->hc.lambda = 100.0;
@@ -782,7 +782,7 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   double *dL = nullptr, *dD = nullptr, *dx = nullptr;
   const size_t ncb = (size_t)npad / nb;
   HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
-  HIP_TRY(hipMalloc((void **)&dD, (ncb * nb * nb + npad) * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&dD, ncb * ba::kDenseWsPerBlock * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dx, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMemcpy(dL, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice));
   hipEvent_t e0, e1;

@@ -34,110 +34,178 @@ __global__ __launch_bounds__(256) void k_dense_init(double *L, int npad, int ld,
 }
 
 // ---- step 1: Cholesky of the 64x64 diagonal block (one workgroup) ---------
-// Blocked by 16 inside LDS.  Writes the factor to Ldiag[kb] (column-major
-// 64x64, strictly-upper part zero) and 1/diag to dinv.
-__global__ __launch_bounds__(256) void k_chol_diag(double *L, int ld, int k0,
-                                                   double *Ldiag_k,
-                                                   double *dinv_k,
+// Left-looking over four 16-column panels held in LDS.  The bulk (panel
+// update, TRSM of the rows below) runs on the fp64 matrix cores; the only
+// serial part is the register-resident 16x16 tile factorisation below, which
+// produces L_T and E_T = L_T^-T in the same 16 steps (the column operations
+// that turn A into L turn I into L^-T).
+//
+// Outputs per block (workspace `ws`, kDenseWsPerBlock doubles):
+//   ws[0 .. 4095]      L11, column-major 64x64, zero above the diagonal
+//   ws[4096 + 256 p..] E_pp = L_pp^-T (16x16, row-major, upper incl. diag)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
+
+// Lane (r = lane&15, q = lane>>4) holds g[j] = G[r][4j+q].  On entry the lower
+// triangle (r >= c) is the SPD tile and the strict upper part is 0; on exit the
+// lower triangle is L_T and the strict upper part is L_T^-T (its diagonal is
+// 1/L_cc and is not stored).  A non-positive pivot zeroes its column.
+__device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int cq = c & 3, cj = c >> 2;
+    const double d = readlane_f64(g[cj], c + 16 * cq);
+    const bool ok = d > 1e-300;
+    const double sd = ok ? sqrt(d) : 0.0;
+    const double inv = ok ? 1.0 / sd : 0.0;
+    const double colv = __shfl(g[cj], r + 16 * cq, 64);
+    const double mr = (r == c) ? inv : colv * inv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c2 = 4 * j + q;
+      const double lc = __shfl(g[cj], c2 + 16 * cq, 64) * inv;
+      const bool upd = (c2 > c) && ((r <= c) || (c2 <= r));
+      if (upd) g[j] -= mr * lc;
+    }
+    if (q == cq) g[cj] = (r == c) ? sd : g[cj] * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
+                                                   int k0, double *ws,
                                                    const int *done) {
   if (done && *done) return;
   constexpr int LS = NB + 1;
-  __shared__ double A[NB * LS];  // A[c*LS + r]
-  __shared__ double inv[NB];
-  const int tid = threadIdx.x;
+  constexpr int ES = 17;
+  __shared__ double Lb[NB * LS];      // Lb[c*LS + r]
+  __shared__ double Eb[4][16 * ES];   // Eb[p][k*ES + c] = E_pp[k][c]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   for (int e = tid; e < NB * NB; e += 256) {
     const int c = e / NB, r = e % NB;
-    A[c * LS + r] = (r >= c) ? L[(size_t)(k0 + c) * ld + k0 + r] : 0.0;
+    Lb[c * LS + r] = (r >= c) ? L[(size_t)(k0 + c) * ld + k0 + r] : 0.0;
   }
+  for (int e = tid; e < 4 * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
   __syncthreads();
-  for (int c0 = 0; c0 < NB; c0 += 16) {
-    // (i) 16x16 diagonal sub-block, lanes 0..15 of wave 0, right-looking
-    if (tid < 64) {
-      for (int c = 0; c < 16; ++c) {
-        const double dcc = A[(c0 + c) * LS + c0 + c];
-        const bool ok = dcc > 1e-300;
-        const double s = ok ? sqrt(dcc) : 0.0;
-        const double iv = ok ? 1.0 / s : 0.0;
-        double l = 0.0;
-        if (tid > c && tid < 16) {
-          l = A[(c0 + c) * LS + c0 + tid] * iv;
-          A[(c0 + c) * LS + c0 + tid] = l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    // (1) left-looking update of panel p: tile (ti,p) -= sum_kt L(ti,kt) L(p,kt)^T
+    if (p > 0) {
+      const int ti = p + wv;
+      if (ti < 4) {
+        v4f64 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr];
+        for (int kc = 0; kc < 16 * p; kc += 4) {
+          const double a = -Lb[(kc + lk) * LS + 16 * p + lr];
+          const double b = Lb[(kc + lk) * LS + 16 * ti + lr];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-        if (tid == c) {
-          A[(c0 + c) * LS + c0 + c] = s;
-          inv[c0 + c] = iv;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid > c && tid < 16)
-          for (int c2 = c + 1; c2 <= tid; ++c2)
-            A[(c0 + c2) * LS + c0 + tid] -= l * A[(c0 + c) * LS + c0 + c2];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr] = acc[g];
+      }
+      __syncthreads();
+    }
+    // (2) factor the diagonal tile (wave 0)
+    if (wv == 0) {
+      const int r = lr, q = lk;
+      double g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * j + q;
+        g[j] = (r >= c) ? Lb[(16 * p + c) * LS + 16 * p + r] : 0.0;
+      }
+      tile16_potrf_inv(g, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * j + q;
+        if (r >= c) Lb[(16 * p + c) * LS + 16 * p + r] = g[j];
+        if (r < c) Eb[p][r * ES + c] = g[j];
+        if (r == c) Eb[p][r * ES + c] = (g[j] > 0.0) ? 1.0 / g[j] : 0.0;
       }
     }
     __syncthreads();
-    const int rem = NB - c0 - 16;  // rows below the sub-block
-    // (ii) TRSM of the rows below: one thread per row
-    if (tid < rem) {
-      const int r = c0 + 16 + tid;
-      double xr[16];
+    // (3) TRSM of the tiles below: X = T * E_pp   (waves 1..3)
+    if (p < 3) {
+      const int ti = p + wv;
+      if (wv >= 1 && ti < 4) {
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        double s = A[(c0 + c) * LS + r];
+        for (int g = 0; g < 4; ++g) {
+          const double a = Eb[p][(lk + 4 * g) * ES + lr];
+          const double b = Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        // all reads of this tile precede the writes within the wave
 #pragma unroll
-        for (int k = 0; k < c; ++k) s -= xr[k] * A[(c0 + k) * LS + c0 + c];
-        xr[c] = s * inv[c0 + c];
+        for (int g = 0; g < 4; ++g)
+          Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr] = acc[g];
       }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) A[(c0 + c) * LS + r] = xr[c];
+      __syncthreads();
     }
-    __syncthreads();
-    // (iii) trailing update inside the block (lower part)
-    for (int e = tid; e < rem * rem; e += 256) {
-      const int rr = e % rem, cc = e / rem;
-      if (rr < cc) continue;
-      const int r = c0 + 16 + rr, c = c0 + 16 + cc;
-      double s = A[c * LS + r];
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        s -= A[(c0 + k) * LS + r] * A[(c0 + k) * LS + c];
-      A[c * LS + r] = s;
-    }
-    __syncthreads();
   }
   for (int e = tid; e < NB * NB; e += 256) {
     const int c = e / NB, r = e % NB;
-    Ldiag_k[e] = (r >= c) ? A[c * LS + r] : 0.0;
+    ws[e] = (r >= c) ? Lb[c * LS + r] : 0.0;
   }
-  if (tid < NB) dinv_k[tid] = inv[tid];
+  for (int e = tid; e < 4 * 256; e += 256) {
+    const int p = e >> 8, k = (e >> 4) & 15, c = e & 15;
+    ws[NB * NB + e] = Eb[p][k * ES + c];
+  }
 }
 
 // ---- step 2: TRSM of the rows below the diagonal block --------------------
-// X = A21 * L11^-T, one thread per row, the row kept in registers; L11 is
-// wave-uniform and read through the scalar path.
+// X = A21 * L11^-T by block forward substitution over the four 16-column
+// panels, entirely on the matrix cores: one wave per 16 rows,
+//   X_p = (A_p - sum_{k<p} X_k L_pk^T) * E_pp.
+// Orientation D[m = column][n = row]: an accumulator register is 16
+// consecutive rows of one column (128 contiguous bytes), and — because the
+// f64 C/D map is row = (lane>>4) + 4*reg — the accumulator of one product is
+// already the B operand of the next (k-step g <-> k = (lane>>4) + 4g).
 __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld, int k0,
-                                                   int n_rows_total,
-                                                   const double *__restrict__ Ld,
-                                                   const double *__restrict__ dinv,
+                                                   int row_limit,
+                                                   const double *__restrict__ ws,
                                                    const int *done) {
   if (done && *done) return;
-  const int r = k0 + NB + blockIdx.x * 256 + threadIdx.x;
-  if (r >= n_rows_total) return;
-  double x[NB];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int r0 = k0 + NB + 16 * (blockIdx.x * 4 + wv);
+  if (r0 >= row_limit) return;
+  const double *Ld = ws;
+  const double *Et = ws + NB * NB;
+  v4f64 X[4];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) x[c] = L[(size_t)(k0 + c) * ld + r];
+  for (int p = 0; p < 4; ++p) {
+    v4f64 acc;
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double s = x[c];
+    for (int g = 0; g < 4; ++g)
+      acc[g] = L[(size_t)(k0 + 16 * p + lk + 4 * g) * ld + r0 + lr];
 #pragma unroll
-    for (int k = 0; k < c; ++k) s -= x[k] * Ld[k * NB + c];
-    x[c] = s * dinv[c];
+    for (int kq = 0; kq < p; ++kq)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double a = -Ld[(16 * kq + lk + 4 * g) * NB + 16 * p + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[kq][g], acc, 0, 0, 0);
+      }
+    v4f64 out = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const double a = Et[p * 256 + (lk + 4 * g) * 16 + lr];
+      out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[g], out, 0, 0, 0);
+    }
+    X[p] = out;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      L[(size_t)(k0 + 16 * p + lk + 4 * g) * ld + r0 + lr] = out[g];
   }
-#pragma unroll
-  for (int c = 0; c < NB; ++c) L[(size_t)(k0 + c) * ld + r] = x[c];
 }
 
 // ---- step 3: trailing update C_IJ -= P_I P_J^T on the fp64 matrix cores ---
@@ -187,13 +255,14 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double *L, int ld, int k0,
 }
 
 // ---- backward sweep L^T x = z, one launch per column block (right-looking) -
-// Every workgroup first solves the 64x64 diagonal system for x_k (wave 0,
-// redundantly); workgroup 0 stores x_k; workgroup g>0 subtracts the strip
+// Every workgroup first solves the 64x64 diagonal system for x_k by block back
+// substitution with the tile inverses E_pp (wave 0, redundantly):
+//   x_p = E_pp (z_p - sum_{t>p} L_tp^T x_t),  p = 3..0;
+// workgroup 0 stores x_k; workgroup g>0 subtracts the strip
 // L[k-block rows, column block g-1]^T x_k from z.
 __global__ __launch_bounds__(256) void k_chol_back(double *L, int ld, int npad,
                                                    int kb,
-                                                   const double *__restrict__ Ld,
-                                                   const double *__restrict__ dinv,
+                                                   const double *__restrict__ ws,
                                                    double *x, int n_x,
                                                    const int *done) {
   if (done && *done) return;
@@ -201,15 +270,36 @@ __global__ __launch_bounds__(256) void k_chol_back(double *L, int ld, int npad,
   __shared__ double part[4][NB];
   const int tid = threadIdx.x;
   const int k0 = kb * NB;
+  const double *Ld = ws;
+  const double *Et = ws + NB * NB;
   if (tid < 64) {
-    double w = L[(size_t)(k0 + tid) * ld + npad];
-    for (int r = NB - 1; r >= 0; --r) {
-      const double xr = __shfl(w * dinv[r], r, 64);
-      if (tid < r) w -= Ld[tid * NB + r] * xr;
-      if (tid == r) w = xr;
+    const int i = tid & 15, q = tid >> 4;
+#pragma unroll
+    for (int p = 3; p >= 0; --p) {
+      double acc = 0.0;
+      for (int t = p + 1; t < 4; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = 16 * t + 4 * q + rr;
+          acc += Ld[(16 * p + i) * NB + row] * xs[row];
+        }
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      const double wv = L[(size_t)(k0 + 16 * p + i) * ld + npad] - acc;
+      double px = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * q + cc;
+        px += Et[p * 256 + i * 16 + c] * __shfl(wv, c, 64);
+      }
+      px += __shfl_xor(px, 16, 64);
+      px += __shfl_xor(px, 32, 64);
+      if (q == 0) xs[16 * p + i] = px;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    xs[tid] = w;
-    if (blockIdx.x == 0 && k0 + tid < n_x) x[k0 + tid] = w;
+    if (blockIdx.x == 0 && k0 + tid < n_x) x[k0 + tid] = xs[tid];
   }
   if (blockIdx.x == 0) return;
   __syncthreads();
@@ -235,30 +325,29 @@ void launch_dense_init(double *L, int npad, int ld, int n_valid,
                      n_valid, done_flag);
 }
 
-// Ldiag: (npad/64) blocks of 64*64 doubles followed by npad doubles of 1/diag.
+// Ldiag: (npad/64) blocks of kDenseWsPerBlock doubles (L11 + tile inverses).
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         int n_x, const int *done, hipStream_t s) {
   const int ncb = npad / NB;
-  double *dinv = Ldiag + (size_t)ncb * NB * NB;
-  const int n_rows_total = npad + 1;  // rows that carry data (rhs = row npad)
+  const int row_limit = npad + 16;  // rows that carry data (rhs = row npad)
   for (int kb = 0; kb < ncb; ++kb) {
     const int k0 = kb * NB;
-    double *Ld = Ldiag + (size_t)kb * NB * NB;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, L, ld, k0, Ld,
-                       dinv + k0, done);
-    const int rows_below = n_rows_total - (k0 + NB);
-    if (rows_below > 0)
-      hipLaunchKernelGGL(k_chol_trsm, dim3((rows_below + 255) / 256), dim3(256),
-                         0, s, L, ld, k0, n_rows_total, Ld, dinv + k0, done);
+    double *ws = Ldiag + (size_t)kb * kDenseWsPerBlock;
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, L, ld, k0, ws,
+                       done);
+    const int waves = (row_limit - (k0 + NB)) / 16;
+    if (waves > 0)
+      hipLaunchKernelGGL(k_chol_trsm, dim3((waves + 3) / 4), dim3(256), 0, s, L,
+                         ld, k0, row_limit, ws, done);
     const int T = ncb - 1 - kb;  // remaining column blocks
     if (T > 0)
       hipLaunchKernelGGL(k_chol_syrk, dim3(T + 1, T), dim3(256), 0, s, L, ld,
                          k0, kb, ncb, done);
   }
   for (int kb = ncb - 1; kb >= 0; --kb) {
-    double *Ld = Ldiag + (size_t)kb * NB * NB;
+    const double *ws = Ldiag + (size_t)kb * kDenseWsPerBlock;
     hipLaunchKernelGGL(k_chol_back, dim3(1 + kb), dim3(256), 0, s, L, ld, npad,
-                       kb, Ld, dinv + kb * NB, x, n_x, done);
+                       kb, ws, x, n_x, done);
   }
 }
 

@@ -95,12 +95,14 @@ struct DevProblem {
   // dense reduced system (exchange buffer 0): column-major lower, ld rows
   double *L;
   int npad, ld;
-  double *Ldiag;   // (npad/64) * 64*64 diagonal factors (column-major)
+  double *Ldiag;   // (npad/64) * kDenseWsPerBlock (diagonal factors + inverses)
 };
 
 constexpr int kCostGrid = 1024;
 constexpr int kLmGrid = 1024;
 constexpr int kDenseNb = 64;
+// dense workspace per 64-column block: L11 (64x64) + four 16x16 tile inverses
+constexpr int kDenseWsPerBlock = 64 * 64 + 4 * 256;
 
 // ---- launchers (ba_kernels.hip) ----
 // sel: 0 = accepted parameters, 1 = trial parameters
