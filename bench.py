@@ -101,18 +101,8 @@ def main():
     p.finalize()
     t_fin = time.time() - t_fin
     if world > 1:
-        bufs = []
-        for which in (0, 1):
-            n = p.reduce_buffer_size(which)
-            t = torch.zeros(n, dtype=torch.float64, device="cuda")
-            p.bind_reduce_buffer(which, t.data_ptr(), n)
-            bufs.append(t)
-        keep.append(bufs)
-
-        def hook(which, ptr, n, stream):
-            dist.all_reduce(bufs[which])
-            return 0
-        p.set_allreduce(hook)
+        from bundle_adjustment_solver_amd.sharding import TorchExchange
+        keep.append(TorchExchange(p, dist, torch.device("cuda", local_rank)))
 
     n_obs = int(pr["obs_cam"].shape[0])
     N = p.N

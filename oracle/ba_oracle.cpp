@@ -841,6 +841,14 @@ void ba_oracle_get_xy(const ba_oracle *o, double *x6, double *y3) {
   if (y3) std::memcpy(y3, o->y.data(), o->y.size() * sizeof(double));
 }
 
+void ba_oracle_set_S(ba_oracle *o, const double *S, const double *rhs) {
+  if (S) std::memcpy(o->S.data(), S, o->S.size() * sizeof(double));
+  if (rhs) std::memcpy(o->rhs.data(), rhs, o->rhs.size() * sizeof(double));
+}
+void ba_oracle_set_x(ba_oracle *o, const double *x6) {
+  std::memcpy(o->x.data(), x6, o->x.size() * sizeof(double));
+}
+
 void ba_oracle_ldlt_solve(int n, const double *A_rowmajor, int nrhs,
                           const double *B_colmajor, double *X_colmajor) {
   Ldlt f;

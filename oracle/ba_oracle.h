@@ -113,6 +113,10 @@ void ba_oracle_get_pairs(const ba_oracle *o, int32_t *pair_i, int32_t *pair_j,
 void ba_oracle_get_S(const ba_oracle *o, double *S /* (6N)^2 row-major */,
                      double *rhs /* 6N */);
 void ba_oracle_get_xy(const ba_oracle *o, double *x6, double *y3);
+/* Overwrite S||rhs / x (tests of the multi-GPU exchange protocol: the reduced
+ * system summed over shards is injected before the dense solve). */
+void ba_oracle_set_S(ba_oracle *o, const double *S, const double *rhs);
+void ba_oracle_set_x(ba_oracle *o, const double *x6);
 
 /* Eigen-style pivoted LDLT solve of a dense symmetric system (lower part
  * read), nrhs right-hand sides, column-major rhs. Exposed for tests. */

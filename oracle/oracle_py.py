@@ -83,6 +83,8 @@ def load():
     L.ba_oracle_get_points.argtypes = [C.c_void_p, _D]
     for n in ("A", "C", "Cinv", "S", "xy"):
         getattr(L, "ba_oracle_get_" + n).argtypes = [C.c_void_p, _D, _D]
+    L.ba_oracle_set_S.argtypes = [C.c_void_p, _D, _D]
+    L.ba_oracle_set_x.argtypes = [C.c_void_p, _D]
     L.ba_oracle_get_pairs.argtypes = [C.c_void_p, _I, _I, _D]
     L.ba_oracle_ldlt_solve.argtypes = [C.c_int, _D, C.c_int, _D, _D]
     L.ba_oracle_pose_only_mono6.restype = C.c_int
@@ -234,6 +236,15 @@ class Oracle:
         S, rhs = np.zeros((n6, n6)), np.zeros(n6)
         self.L.ba_oracle_get_S(self.o, _dp(S), _dp(rhs))
         return S, rhs
+
+    def set_S(self, S, rhs):
+        S = np.ascontiguousarray(S, np.float64)
+        rhs = np.ascontiguousarray(rhs, np.float64)
+        self.L.ba_oracle_set_S(self.o, _dp(S), _dp(rhs))
+
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        self.L.ba_oracle_set_x(self.o, _dp(x))
 
     def get_xy(self):
         x, y = np.zeros((self.N, 6)), np.zeros((self.M, 3))

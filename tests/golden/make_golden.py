@@ -1,0 +1,63 @@
+"""Generates tests/golden/*.json from the CPU oracle.
+
+The reference holds no fixtures for this path and cannot be built or run in
+this image, so these are SELF-GENERATED regression vectors
+(parity unpinned by the reference): they pin the oracle against drift and give
+the GPU tests a committed target.  Re-run: python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from bundle_adjustment_solver_amd import scenes  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def full_ba():
+    scene_args = dict(n_pose=14, n_pt=200, window=5, stereo=True, seed=31,
+                      n_fixed=3)
+    options = dict(max_iter=12, thr_step=0.0, thr_cost=0.0)
+    sc = scenes.synthetic_ba_scene(**scene_args)
+    pr = scenes.scaled_problem(sc)
+    o = O.Oracle(pr)
+    cost0 = o.cost()
+    rows, conv = o.solve(O.make_options(**options))
+    gold = dict(
+        scene_args=scene_args, options=options,
+        n_obs=int(pr["obs_cam"].shape[0]), cost0=cost0,
+        rows=[dict(status=r.iteration_status, trial_cost=r.trial_cost,
+                   cost=r.cost, rho=r.rho, model_change=r.model_change,
+                   abs_step=r.abs_step, **{"lambda": r.damping_term})
+              for r in rows],
+        final_poses=o.get_poses().tolist(),
+        final_points_head=o.get_points()[:40].tolist())
+    with open(os.path.join(HERE, "ba_golden_small.json"), "w") as f:
+        json.dump(gold, f, indent=0)
+
+
+def pose_only():
+    sc = scenes.pose_only_scene(1000, seed=41)
+    opt = O.make_options(max_iter=100, thr_step=1e-6, thr_cost=1e-6,
+                         huber=1.0, outlier=2.5)
+    res = O.pose_only_mono6(sc["X"], sc["uv"], sc["fx"], sc["fy"], sc["cx"],
+                            sc["cy"], sc["T_init"], np.ones(1000, np.uint8),
+                            opt)
+    gold = dict(n=1000, seed=41, n_iter=res["n_iter"],
+                converged=res["converged"],
+                rows=[list(map(float, r)) for r in res["rows"]],
+                T12=res["T12"].astype(float).tolist(),
+                n_inlier=int(res["mask"].sum()))
+    with open(os.path.join(HERE, "pose_only_golden.json"), "w") as f:
+        json.dump(gold, f, indent=0)
+
+
+if __name__ == "__main__":
+    full_ba()
+    pose_only()
+    print("golden fixtures written")
