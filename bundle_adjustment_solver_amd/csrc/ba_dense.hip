@@ -62,18 +62,32 @@ __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
     const int cq = c & 3, cj = c >> 2;
     const double d = readlane_f64(g[cj], c + 16 * cq);
     const bool ok = d > 1e-300;
-    const double sd = ok ? sqrt(d) : 0.0;
-    const double inv = ok ? 1.0 / sd : 0.0;
+    const double ds = ok ? d : 1.0;
+    // The dependent chain pivot -> update -> next pivot only needs 1/d
+    // (v_rcp_f64 + 2 Newton steps): G[r][c2] -= G[r][c] G[c2][c] / d with the
+    // UNSCALED column.  The 1/sqrt(d) scaling of column c is off the chain.
+    double ri = __builtin_amdgcn_rcp(ds);
+    ri = fma(fma(-ds, ri, 1.0), ri, ri);
+    ri = fma(fma(-ds, ri, 1.0), ri, ri);
+    const double rinv = ok ? ri : 0.0;
     const double colv = __shfl(g[cj], r + 16 * cq, 64);
-    const double mr = (r == c) ? inv : colv * inv;
+    const double mr = ((r == c) ? 1.0 : colv) * rinv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c2 = 4 * j + q;
-      const double lc = __shfl(g[cj], c2 + 16 * cq, 64) * inv;
+      const double lc = __shfl(g[cj], c2 + 16 * cq, 64);
       const bool upd = (c2 > c) && ((r <= c) || (c2 <= r));
-      if (upd) g[j] -= mr * lc;
+      if (upd) g[j] = fma(-mr, lc, g[j]);
     }
-    if (q == cq) g[cj] = (r == c) ? sd : g[cj] * inv;
+    // scale column c by 1/sqrt(d) (v_rsq_f64 + Newton), diagonal = sqrt(d)
+    double y = __builtin_amdgcn_rsq(ds);
+    const double hd = 0.5 * ds;
+#pragma unroll
+    for (int nr = 0; nr < 3; ++nr) y = y * fma(-hd * y, y, 1.5);
+    double sq = ds * y;
+    sq = fma(fma(-sq, sq, ds), 0.5 * y, sq);
+    y = fma(fma(-sq, y, 1.0), y, y);
+    if (q == cq) g[cj] = ok ? ((r == c) ? sq : g[cj] * y) : 0.0;
   }
 }
 
