@@ -113,6 +113,32 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """One process must hold ONE HIP/HSA runtime.  The PyTorch-ROCm wheel
+    bundles its own libamdhip64.so (SONAME libamdhip64.so.7, requested by torch
+    as "libamdhip64.so"), while libba_hip.so requests "libamdhip64.so.7": if
+    the system copy were loaded first, a later `import torch` would bring in a
+    second runtime and find no GPU.  When torch is installed (bench.py and the
+    multi-GPU path use it for streams and torch.distributed) its copy is
+    therefore loaded first, without importing torch; both libraries then share
+    it.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libba_hip.so and attach the C-ABI signatures (raises if absent)."""
     global _lib
@@ -124,6 +150,7 @@ def load():
             "__graft_entry__ as g; g.build()'` or `make -C "
             "bundle_adjustment_solver_amd/csrc`. The HIP path has no CPU "
             "fallback." % LIB_PATH)
+    _preload_shared_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
