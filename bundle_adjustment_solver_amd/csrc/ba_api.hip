@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,6 +61,7 @@ struct ba_handle {
   bool ev_ok = false;
   double stage_ms[ST_N] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool lm_begun = false;
+  ba::DenseStructure dense;  // structurally non-zero tiles of the factor
   // pose-only scratch (grown on demand, reused across calls)
   int po_cap_n = 0, po_cap_it = 0;
   float *po_X = nullptr, *po_uv = nullptr, *po_T = nullptr, *po_dbg = nullptr;
@@ -126,7 +128,7 @@ int enqueue_iteration(ba_handle *h) {
   mark(h, 2);
   if (xchg(h, 0)) return -1;
   mark(h, 3);
-  ba::launch_dense_solve(d, s);
+  ba::launch_dense_solve(d, h->dense, s);
   mark(h, 4);
   ba::launch_backsub_update(d, s);
   mark(h, 5);
@@ -410,6 +412,25 @@ int ba_finalize(ba_handle *h) {
   if (h->dalloc(&d.L, (size_t)h->xbuf_n[0])) return -1;
   const size_t ncb = (size_t)d.npad / ba::kDenseNb;
   if (h->dalloc(&d.Ldiag, ncb * ba::kDenseWsPerBlock)) return -1;
+  {
+    // tile pattern of S -> per-step lists (BA_DENSE_FULL=1 forces the dense
+    // sweep, e.g. to measure the matrix-core kernels on the full matrix)
+    std::vector<uint8_t> nz((size_t)ncb * ncb, 0);
+    const char *full = getenv("BA_DENSE_FULL");
+    const bool dense_full = full && atoi(full) != 0;
+    for (size_t I = 0; I < ncb; ++I)
+      for (size_t J = 0; J <= I; ++J)
+        nz[I * ncb + J] = dense_full || (I < (size_t)pl.ncb && J < (size_t)pl.ncb &&
+                                         pl.tile_nz[I * pl.ncb + J]) || I == J;
+    std::vector<int> rows, cols;
+    ba::build_dense_structure((int)ncb, nz, h->dense.h_row_ptr, rows,
+                              h->dense.h_col_ptr, cols);
+    size_t cnt = 0;
+    for (size_t I = 0; I < ncb; ++I)
+      for (size_t J = 0; J <= I; ++J) cnt += nz[I * ncb + J];
+    h->dense.fill = (double)cnt / (double)(ncb * (ncb + 1) / 2);
+    if (h->upload(&h->dense.d_rows, rows) || h->upload(&h->dense.d_cols, cols)) return -1;
+  }
 
   std::memset(&h->hc, 0, sizeof(h->hc));
   h->hc.lambda = 100.0;
@@ -572,7 +593,7 @@ int ba_stage_schur(ba_handle *h) {
 int ba_stage_solve_reduced(ba_handle *h) {
   if (!h || !h->finalized) return fail("ba_stage_solve_reduced: not finalized");
   if (use_device(h)) return -1;
-  ba::launch_dense_solve(h->d, h->stream);
+  ba::launch_dense_solve(h->d, h->dense, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -785,11 +806,30 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   HIP_TRY(hipMalloc((void **)&dD, ncb * ba::kDenseWsPerBlock * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dx, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMemcpy(dL, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice));
+  ba::DenseStructure st;
+  {
+    std::vector<uint8_t> nz(ncb * ncb, 0);
+    for (size_t I = 0; I < ncb; ++I)
+      for (size_t J = 0; J <= I; ++J) {
+        bool any = (I == J);
+        for (int c = (int)J * nb; c < (int)(J + 1) * nb && !any; ++c)
+          for (int r = (int)I * nb; r < (int)(I + 1) * nb && !any; ++r)
+            any = r >= c && L[(size_t)c * ld + r] != 0.0;
+        nz[I * ncb + J] = any;
+      }
+    std::vector<int> rows, cols;
+    ba::build_dense_structure((int)ncb, nz, st.h_row_ptr, rows, st.h_col_ptr, cols);
+    HIP_TRY(hipMalloc((void **)&st.d_rows, std::max<size_t>(1, rows.size()) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&st.d_cols, std::max<size_t>(1, cols.size()) * sizeof(int)));
+    HIP_TRY(hipMemcpy(st.d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!cols.empty())
+      HIP_TRY(hipMemcpy(st.d_cols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, h->stream));
-  ba::dense_factor_solve(dL, npad, ld, dD, dx, n, nullptr, h->stream);
+  ba::dense_factor_solve(dL, npad, ld, dD, dx, n, nullptr, st, h->stream);
   HIP_TRY(hipEventRecord(e1, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   float t = 0.f;
@@ -801,6 +841,8 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   (void)hipFree(dL);
   (void)hipFree(dD);
   (void)hipFree(dx);
+  (void)hipFree(st.d_rows);
+  (void)hipFree(st.d_cols);
   HIP_TRY(hipGetLastError());
   return 0;
 }

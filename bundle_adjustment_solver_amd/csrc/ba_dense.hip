@@ -14,6 +14,8 @@
 // component are set to zero.
 #include "ba_device.h"
 
+#include <vector>
+
 namespace ba {
 
 namespace {
@@ -186,12 +188,14 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
 // already the B operand of the next (k-step g <-> k = (lane>>4) + 4g).
 __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld, int k0,
                                                    int row_limit,
+                                                   const int *__restrict__ rows,
                                                    const double *__restrict__ ws,
                                                    const int *done) {
   if (done && *done) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const int r0 = k0 + NB + 16 * (blockIdx.x * 4 + wv);
+  // one workgroup per structurally non-zero 64-row tile of the panel
+  const int r0 = rows[blockIdx.x] * NB + 16 * wv;
   if (r0 >= row_limit) return;
   const double *Ld = ws;
   const double *Et = ws + NB * NB;
@@ -228,13 +232,14 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld, int k0,
 // "column" index (lane&15) over C's ROW i, so that each accumulator register
 // is 16 consecutive rows of one column = 128 contiguous bytes in memory.
 __global__ __launch_bounds__(256) void k_chol_syrk(double *L, int ld, int k0,
-                                                   int kb, int ncb,
+                                                   int ncb,
+                                                   const int *__restrict__ rows,
                                                    const int *done) {
   if (done && *done) return;
-  const int Ip = blockIdx.x, Jp = blockIdx.y;  // tile offsets past block kb
-  if (Jp > Ip) return;
-  const int I = kb + 1 + Ip, J = kb + 1 + Jp;
-  if (J >= ncb) return;  // the rhs row block has no diagonal tile
+  // tile (I, J) = (rows[x], rows[y]) of the structurally non-zero row tiles of
+  // panel k; the last list entry is the rhs row block `ncb` (no diagonal tile)
+  const int I = rows[blockIdx.x], J = rows[blockIdx.y];
+  if (J > I || J >= ncb) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = wv & 1, wj = wv >> 1;
   const int i0 = I * NB + 32 * wi, j0 = J * NB + 32 * wj;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(256) void k_chol_back(double *L, int ld, int npad,
                                                    int kb,
                                                    const double *__restrict__ ws,
                                                    double *x, int n_x,
+                                                   const int *__restrict__ cols,
                                                    const int *done) {
   if (done && *done) return;
   __shared__ double xs[NB];
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void k_chol_back(double *L, int ld, int npad,
   }
   if (blockIdx.x == 0) return;
   __syncthreads();
-  const int cb = blockIdx.x - 1;
+  const int cb = cols[blockIdx.x - 1];  // structurally non-zero tile (kb, cb)
   const int c = cb * NB + (tid & 63), q = tid >> 6;
   const double *col = L + (size_t)c * ld + k0 + 16 * q;
   double s = 0.0;
@@ -340,8 +346,18 @@ void launch_dense_init(double *L, int npad, int ld, int n_valid,
 }
 
 // Ldiag: (npad/64) blocks of kDenseWsPerBlock doubles (L11 + tile inverses).
+//
+// STRUCTURE-AWARE: the reduced camera matrix is block sparse (two poses couple
+// only through landmarks they both see).  `st` holds, per 64-column step k,
+// the list of row tiles that are structurally non-zero in the FACTOR (tile
+// pattern of S closed under symbolic Cholesky fill, computed once on the
+// host); TRSM, the trailing update and the backward strips touch only those
+// tiles.  Zero tiles stay exactly zero in a dense factorisation too, so the
+// result is bit-identical to the dense sweep; a dense pattern degenerates to
+// it.
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
-                        int n_x, const int *done, hipStream_t s) {
+                        int n_x, const int *done, const DenseStructure &st,
+                        hipStream_t s) {
   const int ncb = npad / NB;
   const int row_limit = npad + 16;  // rows that carry data (rhs = row npad)
   for (int kb = 0; kb < ncb; ++kb) {
@@ -349,25 +365,53 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
     double *ws = Ldiag + (size_t)kb * kDenseWsPerBlock;
     hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, L, ld, k0, ws,
                        done);
-    const int waves = (row_limit - (k0 + NB)) / 16;
-    if (waves > 0)
-      hipLaunchKernelGGL(k_chol_trsm, dim3((waves + 3) / 4), dim3(256), 0, s, L,
-                         ld, k0, row_limit, ws, done);
-    const int T = ncb - 1 - kb;  // remaining column blocks
-    if (T > 0)
-      hipLaunchKernelGGL(k_chol_syrk, dim3(T + 1, T), dim3(256), 0, s, L, ld,
-                         k0, kb, ncb, done);
+    const int nr = st.h_row_ptr[kb + 1] - st.h_row_ptr[kb];  // incl. rhs block
+    const int *rows = st.d_rows + st.h_row_ptr[kb];
+    hipLaunchKernelGGL(k_chol_trsm, dim3(nr), dim3(256), 0, s, L, ld, k0,
+                       row_limit, rows, ws, done);
+    if (nr > 1)
+      hipLaunchKernelGGL(k_chol_syrk, dim3(nr, nr - 1), dim3(256), 0, s, L, ld,
+                         k0, ncb, rows, done);
   }
   for (int kb = ncb - 1; kb >= 0; --kb) {
     const double *ws = Ldiag + (size_t)kb * kDenseWsPerBlock;
-    hipLaunchKernelGGL(k_chol_back, dim3(1 + kb), dim3(256), 0, s, L, ld, npad,
-                       kb, ws, x, n_x, done);
+    const int nc = st.h_col_ptr[kb + 1] - st.h_col_ptr[kb];
+    hipLaunchKernelGGL(k_chol_back, dim3(1 + nc), dim3(256), 0, s, L, ld, npad,
+                       kb, ws, x, n_x, st.d_cols + st.h_col_ptr[kb], done);
   }
 }
 
-void launch_dense_solve(const DevProblem &d, hipStream_t s) {
+// Tile pattern -> per-step lists.  `nz[I*ncb + J]` (I >= J) marks non-zero
+// 64x64 tiles of the lower triangle; it is closed under fill-in here.
+void build_dense_structure(int ncb, std::vector<uint8_t> &nz,
+                           std::vector<int> &row_ptr, std::vector<int> &rows,
+                           std::vector<int> &col_ptr, std::vector<int> &cols) {
+  row_ptr.assign(ncb + 1, 0);
+  rows.clear();
+  std::vector<int> rk;
+  for (int k = 0; k < ncb; ++k) {
+    rk.clear();
+    for (int I = k + 1; I < ncb; ++I)
+      if (nz[(size_t)I * ncb + k]) rk.push_back(I);
+    for (size_t a = 0; a < rk.size(); ++a)       // symbolic fill
+      for (size_t b = 0; b <= a; ++b) nz[(size_t)rk[a] * ncb + rk[b]] = 1;
+    for (int I : rk) rows.push_back(I);
+    rows.push_back(ncb);                          // the rhs row block
+    row_ptr[k + 1] = (int)rows.size();
+  }
+  col_ptr.assign(ncb + 1, 0);
+  cols.clear();
+  for (int k = 0; k < ncb; ++k) {
+    for (int c = 0; c < k; ++c)
+      if (nz[(size_t)k * ncb + c]) cols.push_back(c);
+    col_ptr[k + 1] = (int)cols.size();
+  }
+}
+
+void launch_dense_solve(const DevProblem &d, const DenseStructure &st,
+                        hipStream_t s) {
   dense_factor_solve(d.L, d.npad, d.ld, d.Ldiag, d.x, 6 * d.N, &d.ctrl->done,
-                     s);
+                     st, s);
 }
 
 }  // namespace ba

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace ba {
 
 // LM controller state, resident in device memory so that a whole batch of
@@ -117,10 +119,23 @@ void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s);
 // ---- dense solver (ba_dense.hip) ----
 // Factor the npad x npad lower matrix in d.L (with the rhs carried as row
 // `npad`) and write x (first 6N entries).
-void launch_dense_solve(const DevProblem &d, hipStream_t s);
-// stand-alone helpers for ba_dense_spd_solve
+// Per-step lists of structurally non-zero 64x64 tiles of the factor (host
+// copies of the CSR pointers for grid sizes, device copies of the lists).
+struct DenseStructure {
+  std::vector<int> h_row_ptr, h_col_ptr;  // ncb+1 each
+  int *d_rows = nullptr;                  // row tiles per step (+ rhs block)
+  int *d_cols = nullptr;                  // column tiles per backward step
+  double fill = 1.0;                      // non-zero tiles / all lower tiles
+};
+void build_dense_structure(int ncb, std::vector<uint8_t> &nz,
+                           std::vector<int> &row_ptr, std::vector<int> &rows,
+                           std::vector<int> &col_ptr, std::vector<int> &cols);
+void launch_dense_solve(const DevProblem &d, const DenseStructure &st,
+                        hipStream_t s);
+// stand-alone helper for ba_dense_spd_solve
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
-                        int n_x, const int *done_flag, hipStream_t s);
+                        int n_x, const int *done_flag,
+                        const DenseStructure &st, hipStream_t s);
 void launch_dense_init(double *L, int npad, int ld, int n_valid,
                        const int *done_flag, hipStream_t s);
 

@@ -319,6 +319,47 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     make_chunks(pl.sblk_tri_ptr, (int)pl.B, kTriChunk, pl.tchunk_blk,
                 pl.tchunk_begin, pl.tchunk_end, pl.sblk_tchunk_ptr);
   }
+
+  // ---- tile pattern of S (global: every shard factors the same matrix) ----
+  {
+    const int n6 = 6 * N;
+    pl.ncb = std::max(1, (n6 + kDenseTile - 1) / kDenseTile);
+    const int ncb = pl.ncb;
+    pl.tile_nz.assign((size_t)ncb * ncb, 0);
+    for (int t = 0; t < ncb; ++t) pl.tile_nz[(size_t)t * ncb + t] = 1;
+    auto mark = [&](int j, int k) {  // optimised poses j <= k are coupled
+      const int a0 = (6 * j) / kDenseTile, a1 = (6 * j + 5) / kDenseTile;
+      const int b0 = (6 * k) / kDenseTile, b1 = (6 * k + 5) / kDenseTile;
+      for (int a = a0; a <= a1; ++a)
+        for (int b = b0; b <= b1; ++b) {
+          const int I = std::max(a, b), J = std::min(a, b);
+          pl.tile_nz[(size_t)I * ncb + J] = 1;
+        }
+    };
+    if (in.world == 1) {
+      for (int64_t bk = 0; bk < pl.B; ++bk) mark(pl.sblk_j[bk], pl.sblk_k[bk]);
+    } else {
+      // all (landmark, pose) pairs of the FULL problem, both optimisable
+      std::vector<uint64_t> keys;
+      keys.reserve(in.n_obs);
+      for (int64_t k = 0; k < in.n_obs; ++k) {
+        const int j = pl.pose_int_of_user[in.obs_pose[k]];
+        if (j < N && !in.pt_fixed[in.obs_pt[k]])
+          keys.push_back(((uint64_t)(uint32_t)in.obs_pt[k] << 32) | (uint32_t)j);
+      }
+      std::sort(keys.begin(), keys.end());
+      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+      size_t a = 0;
+      while (a < keys.size()) {
+        size_t b = a;
+        while (b < keys.size() && (keys[b] >> 32) == (keys[a] >> 32)) ++b;
+        for (size_t u = a; u < b; ++u)
+          for (size_t v = u; v < b; ++v)
+            mark((int)(uint32_t)keys[u], (int)(uint32_t)keys[v]);
+        a = b;
+      }
+    }
+  }
   return std::string();
 }
 
