@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/ba_hip.h"
+#include "ba_dense_sched.h"
 #include "ba_device.h"
 #include "ba_plan.h"
 
@@ -61,7 +62,9 @@ struct ba_handle {
   bool ev_ok = false;
   double stage_ms[ST_N] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool lm_begun = false;
-  ba::DenseStructure dense;  // structurally non-zero tiles of the factor
+  ba::DenseSchedule sched;   // level schedule of the reduced-system Cholesky
+  ba::DenseDev ddev;
+  std::vector<int> pose_col_h;
   // pose-only scratch (grown on demand, reused across calls)
   int po_cap_n = 0, po_cap_it = 0;
   float *po_X = nullptr, *po_uv = nullptr, *po_T = nullptr, *po_dbg = nullptr;
@@ -128,7 +131,7 @@ int enqueue_iteration(ba_handle *h) {
   mark(h, 2);
   if (xchg(h, 0)) return -1;
   mark(h, 3);
-  ba::launch_dense_solve(d, h->dense, s);
+  ba::launch_dense_solve(d, h->sched, h->ddev, s);
   mark(h, 4);
   ba::launch_backsub_update(d, s);
   mark(h, 5);
@@ -216,7 +219,9 @@ void ba_destroy(ba_handle *h) {
 
 int ba_set_stream(ba_handle *h, void *hip_stream) {
   if (!h) return fail("null handle");
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  // the given value is used as is: NULL is HIP's (legacy) default stream, which
+  // is also what torch.cuda.current_stream().cuda_stream reports by default
+  h->stream = (hipStream_t)hip_stream;
   return 0;
 }
 
@@ -403,33 +408,40 @@ int ba_finalize(ba_handle *h) {
   d.log_cap = 4096;
   if (h->dalloc(&d.log, (size_t)d.log_cap)) return -1;
 
-  // dense reduced system
-  const int n6 = 6 * pl.N;
-  d.npad = std::max(ba::kDenseNb, ((n6 + ba::kDenseNb - 1) / ba::kDenseNb) * ba::kDenseNb);
-  d.ld = d.npad + ba::kDenseNb;
-  h->xbuf_n[0] = (int64_t)d.npad * d.ld;
-  h->xbuf_n[1] = 4;
-  if (h->dalloc(&d.L, (size_t)h->xbuf_n[0])) return -1;
-  const size_t ncb = (size_t)d.npad / ba::kDenseNb;
-  if (h->dalloc(&d.Ldiag, ncb * ba::kDenseWsPerBlock)) return -1;
+  // dense reduced system: tiles of kPosesPerTile poses (60 columns + 4 pad),
+  // eliminated in the order of the level schedule
   {
-    // tile pattern of S -> per-step lists (BA_DENSE_FULL=1 forces the dense
-    // sweep, e.g. to measure the matrix-core kernels on the full matrix)
-    std::vector<uint8_t> nz((size_t)ncb * ncb, 0);
+    const int ncb = pl.ncb;
+    const char *nat = getenv("BA_DENSE_NATURAL");
     const char *full = getenv("BA_DENSE_FULL");
-    const bool dense_full = full && atoi(full) != 0;
-    for (size_t I = 0; I < ncb; ++I)
-      for (size_t J = 0; J <= I; ++J)
-        nz[I * ncb + J] = dense_full || (I < (size_t)pl.ncb && J < (size_t)pl.ncb &&
-                                         pl.tile_nz[I * pl.ncb + J]) || I == J;
-    std::vector<int> rows, cols;
-    ba::build_dense_structure((int)ncb, nz, h->dense.h_row_ptr, rows,
-                              h->dense.h_col_ptr, cols);
-    size_t cnt = 0;
-    for (size_t I = 0; I < ncb; ++I)
-      for (size_t J = 0; J <= I; ++J) cnt += nz[I * ncb + J];
-    h->dense.fill = (double)cnt / (double)(ncb * (ncb + 1) / 2);
-    if (h->upload(&h->dense.d_rows, rows) || h->upload(&h->dense.d_cols, cols)) return -1;
+    std::vector<uint8_t> adj(pl.tile_nz);
+    if (full && atoi(full) != 0) std::fill(adj.begin(), adj.end(), 1);
+    ba::build_dense_schedule(ncb, adj, nat && atoi(nat) != 0, h->sched);
+    d.npad = ncb * ba::kDenseNb;
+    d.ld = d.npad + ba::kDenseNb;
+    h->xbuf_n[0] = (int64_t)d.npad * d.ld;
+    h->xbuf_n[1] = 4;
+    if (h->dalloc(&d.L, (size_t)h->xbuf_n[0])) return -1;
+    if (h->dalloc(&d.Ldiag, (size_t)ncb * ba::kDenseWsPerBlock)) return -1;
+    h->pose_col_h.assign(pl.N, 0);
+    std::vector<int> col_x((size_t)d.npad, -1);
+    for (int j = 0; j < pl.N; ++j) {
+      const int c0 = h->sched.pos_of_tile[j / ba::kPosesPerTile] * ba::kDenseNb +
+                     6 * (j % ba::kPosesPerTile);
+      h->pose_col_h[j] = c0;
+      for (int r = 0; r < 6; ++r) col_x[c0 + r] = 6 * j + r;
+    }
+    const ba::DenseSchedule &sc = h->sched;
+    ba::DenseDev &dd = h->ddev;
+    if (h->upload(&d.pose_col, h->pose_col_h) || h->upload(&d.col_x, col_x) ||
+        h->upload(&dd.row_ptr, sc.row_ptr) || h->upload(&dd.rows, sc.rows) ||
+        h->upload(&dd.item_t, sc.item_t) || h->upload(&dd.item_I, sc.item_I) ||
+        h->upload(&dd.tgt_I, sc.tgt_I) || h->upload(&dd.tgt_J, sc.tgt_J) ||
+        h->upload(&dd.tgt_src_ptr, sc.tgt_src_ptr) || h->upload(&dd.src_t, sc.src_t) ||
+        h->dalloc(&dd.xc, (size_t)d.npad))
+      return -1;
+    dd.col_x = d.col_x;
+    HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
   }
 
   std::memset(&h->hc, 0, sizeof(h->hc));
@@ -593,7 +605,7 @@ int ba_stage_schur(ba_handle *h) {
 int ba_stage_solve_reduced(ba_handle *h) {
   if (!h || !h->finalized) return fail("ba_stage_solve_reduced: not finalized");
   if (use_device(h)) return -1;
-  ba::launch_dense_solve(h->d, h->dense, h->stream);
+  ba::launch_dense_solve(h->d, h->sched, h->ddev, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -752,15 +764,18 @@ int ba_get_S(ba_handle *h, double *S, double *rhs) {
   const int n6 = 6 * h->plan.N;
   std::vector<double> L;
   if (download(L, d.L, (size_t)d.npad * d.ld, h->stream)) return -1;
+  auto colof = [&](int e) { return h->pose_col_h[e / 6] + e % 6; };
   for (int c = 0; c < n6; ++c) {
     for (int r = c; r < n6; ++r) {
-      const double v = L[(size_t)c * d.ld + r];
+      int rr = colof(r), cc = colof(c);
+      if (rr < cc) std::swap(rr, cc);
+      const double v = L[(size_t)cc * d.ld + rr];
       if (S) {
         S[(size_t)r * n6 + c] = v;
         S[(size_t)c * n6 + r] = v;
       }
     }
-    if (rhs) rhs[c] = L[(size_t)c * d.ld + d.npad];
+    if (rhs) rhs[c] = L[(size_t)colof(c) * d.ld + d.npad];
   }
   return 0;
 }
@@ -784,52 +799,72 @@ int ba_get_xy(ba_handle *h, double *x6, double *y3) {
 }
 
 // ---------------------------------------------------------------------------
+int ba_get_dense_info(ba_handle *h, double out4[4]) {
+  if (!h || !h->finalized || !out4) return fail("ba_get_dense_info: bad argument");
+  out4[0] = h->sched.fill;
+  out4[1] = h->sched.flops;
+  out4[2] = (double)h->sched.nlev;
+  out4[3] = (double)h->d.npad;
+  return 0;
+}
+
 int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
                        double *x, double *ms) {
   if (!h || n <= 0 || !A || !b || !x) return fail("ba_dense_spd_solve: bad argument");
   if (use_device(h)) return -1;
   const int nb = ba::kDenseNb;
-  const int npad = ((n + nb - 1) / nb) * nb;
+  const int ncb = (n + nb - 1) / nb;
+  const int npad = ncb * nb;
   const int ld = npad + nb;
+  // tile pattern of A -> level schedule -> symmetric tile permutation
+  std::vector<uint8_t> adj((size_t)ncb * ncb, 0);
+  for (int I = 0; I < ncb; ++I)
+    for (int J = 0; J < I; ++J) {
+      bool any = false;
+      for (int r = I * nb; r < std::min(n, (I + 1) * nb) && !any; ++r)
+        for (int c = J * nb; c < (J + 1) * nb && !any; ++c) any = A[(size_t)r * n + c] != 0.0;
+      adj[(size_t)I * ncb + J] = adj[(size_t)J * ncb + I] = any;
+    }
+  ba::DenseSchedule sc;
+  const char *nat = getenv("BA_DENSE_NATURAL");
+  ba::build_dense_schedule(ncb, adj, nat && atoi(nat) != 0, sc);
+  std::vector<int> colmap(npad), col_x(npad, -1);  // original column -> dense column
+  for (int c = 0; c < npad; ++c) colmap[c] = sc.pos_of_tile[c / nb] * nb + c % nb;
   std::vector<double> L((size_t)npad * ld, 0.0);
   for (int c = 0; c < npad; ++c) {
     if (c < n) {
-      for (int r = c; r < n; ++r) L[(size_t)c * ld + r] = A[(size_t)r * n + c];
-      L[(size_t)c * ld + npad] = b[c];
+      col_x[colmap[c]] = c;
+      for (int r = c; r < n; ++r) {
+        int rr = colmap[r], cc = colmap[c];
+        if (rr < cc) std::swap(rr, cc);
+        L[(size_t)cc * ld + rr] = A[(size_t)r * n + c];
+      }
+      L[(size_t)colmap[c] * ld + npad] = b[c];
     } else {
-      L[(size_t)c * ld + c] = 1.0;
+      L[(size_t)colmap[c] * ld + colmap[c]] = 1.0;
     }
   }
   double *dL = nullptr, *dD = nullptr, *dx = nullptr;
-  const size_t ncb = (size_t)npad / nb;
+  ba::DenseDev dd;
+  auto up = [&](int **p, const std::vector<int> &v) -> int {
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(1, v.size()) * sizeof(int)));
+    if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (up(&dd.row_ptr, sc.row_ptr) || up(&dd.rows, sc.rows) || up(&dd.item_t, sc.item_t) ||
+      up(&dd.item_I, sc.item_I) || up(&dd.tgt_I, sc.tgt_I) || up(&dd.tgt_J, sc.tgt_J) ||
+      up(&dd.tgt_src_ptr, sc.tgt_src_ptr) || up(&dd.src_t, sc.src_t) || up(&dd.col_x, col_x))
+    return -1;
+  HIP_TRY(hipMalloc((void **)&dd.xc, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
-  HIP_TRY(hipMalloc((void **)&dD, ncb * ba::kDenseWsPerBlock * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&dD, (size_t)ncb * ba::kDenseWsPerBlock * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dx, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMemcpy(dL, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice));
-  ba::DenseStructure st;
-  {
-    std::vector<uint8_t> nz(ncb * ncb, 0);
-    for (size_t I = 0; I < ncb; ++I)
-      for (size_t J = 0; J <= I; ++J) {
-        bool any = (I == J);
-        for (int c = (int)J * nb; c < (int)(J + 1) * nb && !any; ++c)
-          for (int r = (int)I * nb; r < (int)(I + 1) * nb && !any; ++r)
-            any = r >= c && L[(size_t)c * ld + r] != 0.0;
-        nz[I * ncb + J] = any;
-      }
-    std::vector<int> rows, cols;
-    ba::build_dense_structure((int)ncb, nz, st.h_row_ptr, rows, st.h_col_ptr, cols);
-    HIP_TRY(hipMalloc((void **)&st.d_rows, std::max<size_t>(1, rows.size()) * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&st.d_cols, std::max<size_t>(1, cols.size()) * sizeof(int)));
-    HIP_TRY(hipMemcpy(st.d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (!cols.empty())
-      HIP_TRY(hipMemcpy(st.d_cols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice));
-  }
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, h->stream));
-  ba::dense_factor_solve(dL, npad, ld, dD, dx, n, nullptr, st, h->stream);
+  ba::dense_factor_solve(dL, npad, ld, dD, dx, nullptr, sc, dd, h->stream);
   HIP_TRY(hipEventRecord(e1, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   float t = 0.f;
@@ -838,15 +873,13 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   HIP_TRY(hipMemcpy(x, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  (void)hipFree(dL);
-  (void)hipFree(dD);
-  (void)hipFree(dx);
-  (void)hipFree(st.d_rows);
-  (void)hipFree(st.d_cols);
+  for (void *p : {(void *)dL, (void *)dD, (void *)dx, (void *)dd.xc, (void *)dd.row_ptr,
+                  (void *)dd.rows, (void *)dd.item_t, (void *)dd.item_I, (void *)dd.tgt_I,
+                  (void *)dd.tgt_J, (void *)dd.tgt_src_ptr, (void *)dd.src_t, (void *)dd.col_x})
+    (void)hipFree(p);
   HIP_TRY(hipGetLastError());
   return 0;
 }
-
 
 int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
                        float fx, float fy, float cx, float cy, float *T12,

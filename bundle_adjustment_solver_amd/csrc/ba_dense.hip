@@ -13,6 +13,7 @@
 // treated like Eigen's pseudo-inverted D entry: the column and the solution
 // component are set to zero.
 #include "ba_device.h"
+#include "ba_dense_sched.h"
 
 #include <vector>
 
@@ -24,12 +25,12 @@ constexpr int NB = kDenseNb;  // 64
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_dense_init(double *L, int npad, int ld,
-                                                    int n_valid,
+                                                    const int *__restrict__ col_x,
                                                     const int *done) {
   if (done && *done) return;
   for (int c = blockIdx.x; c < npad; c += gridDim.x) {
     double *col = L + (size_t)c * ld;
-    const bool pad = c >= n_valid;
+    const bool pad = col_x[c] < 0;  // padding column: unit diagonal
     for (int r = threadIdx.x; r < ld; r += blockDim.x)
       col[r] = (pad && r == c) ? 1.0 : 0.0;
   }
@@ -94,9 +95,12 @@ __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
 }
 
 __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
-                                                   int k0, double *ws,
+                                                   int t0, double *ws_all,
                                                    const int *done) {
   if (done && *done) return;
+  // one workgroup per diagonal tile of the level (independent tiles)
+  const int k0 = (t0 + blockIdx.x) * NB;
+  double *ws = ws_all + (size_t)(t0 + blockIdx.x) * kDenseWsPerBlock;
   constexpr int LS = NB + 1;
   constexpr int ES = 17;
   __shared__ double Lb[NB * LS];      // Lb[c*LS + r]
@@ -186,17 +190,21 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
 // consecutive rows of one column (128 contiguous bytes), and — because the
 // f64 C/D map is row = (lane>>4) + 4*reg — the accumulator of one product is
 // already the B operand of the next (k-step g <-> k = (lane>>4) + 4g).
-__global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld, int k0,
-                                                   int row_limit,
-                                                   const int *__restrict__ rows,
-                                                   const double *__restrict__ ws,
+__global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
+                                                   int row_limit, int it0,
+                                                   const int *__restrict__ item_t,
+                                                   const int *__restrict__ item_I,
+                                                   const double *__restrict__ ws_all,
                                                    const int *done) {
   if (done && *done) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  // one workgroup per structurally non-zero 64-row tile of the panel
-  const int r0 = rows[blockIdx.x] * NB + 16 * wv;
+  // one workgroup per structurally non-zero 64-row tile (t, I) of the level
+  const int t = item_t[it0 + blockIdx.x];
+  const int k0 = t * NB;
+  const int r0 = item_I[it0 + blockIdx.x] * NB + 16 * wv;
   if (r0 >= row_limit) return;
+  const double *ws = ws_all + (size_t)t * kDenseWsPerBlock;
   const double *Ld = ws;
   const double *Et = ws + NB * NB;
   v4f64 X[4];
@@ -226,20 +234,23 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld, int k0,
   }
 }
 
-// ---- step 3: trailing update C_IJ -= P_I P_J^T on the fp64 matrix cores ---
-// 64x64 tile per workgroup, 4 waves of 32x32 (2x2 MFMA 16x16x4 tiles).
+// ---- step 3: trailing update on the fp64 matrix cores ---------------------
+// TARGET-centric: one workgroup per 64x64 tile (I,J) touched in this level;
+// it sums the contributions P_I P_J^T of every source panel of the level that
+// reaches it (ascending position: deterministic) and applies them with ONE
+// read-modify-write.  4 waves of 32x32 (2x2 MFMA 16x16x4 tiles).
 // MFMA orientation: the MFMA "row" index runs over C's COLUMN j and the MFMA
 // "column" index (lane&15) over C's ROW i, so that each accumulator register
 // is 16 consecutive rows of one column = 128 contiguous bytes in memory.
-__global__ __launch_bounds__(256) void k_chol_syrk(double *L, int ld, int k0,
-                                                   int ncb,
-                                                   const int *__restrict__ rows,
-                                                   const int *done) {
+__global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
+                                                     const int *__restrict__ tgt_I,
+                                                     const int *__restrict__ tgt_J,
+                                                     const int *__restrict__ tgt_src_ptr,
+                                                     const int *__restrict__ src_t,
+                                                     const int *done) {
   if (done && *done) return;
-  // tile (I, J) = (rows[x], rows[y]) of the structurally non-zero row tiles of
-  // panel k; the last list entry is the rhs row block `ncb` (no diagonal tile)
-  const int I = rows[blockIdx.x], J = rows[blockIdx.y];
-  if (J > I || J >= ncb) return;
+  const int tg = tg0 + blockIdx.x;
+  const int I = tgt_I[tg], J = tgt_J[tg];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = wv & 1, wj = wv >> 1;
   const int i0 = I * NB + 32 * wi, j0 = J * NB + 32 * wj;
@@ -249,16 +260,18 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double *L, int ld, int k0,
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  const double *P = L + (size_t)k0 * ld;
+  for (int sidx = tgt_src_ptr[tg]; sidx < tgt_src_ptr[tg + 1]; ++sidx) {
+    const double *P = L + (size_t)src_t[sidx] * NB * ld;
 #pragma unroll 4
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    const double *col = P + (size_t)(kk * 4 + lk) * ld;
-    const double a0 = col[j0 + lr], a1 = col[j0 + 16 + lr];
-    const double b0 = col[i0 + lr], b1 = col[i0 + 16 + lr];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double *col = P + (size_t)(kk * 4 + lk) * ld;
+      const double a0 = col[j0 + lr], a1 = col[j0 + 16 + lr];
+      const double b0 = col[i0 + lr], b1 = col[i0 + 16 + lr];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -273,44 +286,64 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double *L, int ld, int k0,
       }
 }
 
-// ---- backward sweep L^T x = z, one launch per column block (right-looking) -
-// Every workgroup first solves the 64x64 diagonal system for x_k by block back
-// substitution with the tile inverses E_pp (wave 0, redundantly):
-//   x_p = E_pp (z_p - sum_{t>p} L_tp^T x_t),  p = 3..0;
-// workgroup 0 stores x_k; workgroup g>0 subtracts the strip
-// L[k-block rows, column block g-1]^T x_k from z.
-__global__ __launch_bounds__(256) void k_chol_back(double *L, int ld, int npad,
-                                                   int kb,
-                                                   const double *__restrict__ ws,
-                                                   double *x, int n_x,
-                                                   const int *__restrict__ cols,
+// ---- backward sweep L^T x = z, one launch per level (reverse order) --------
+// Left-looking: the workgroup of tile t gathers  w = z_t - sum_I L(I,t)^T x_I
+// over the non-zero row tiles I below t (all solved in earlier launches), then
+// wave 0 solves the 64x64 diagonal system by block back substitution with the
+// tile inverses:  x_p = E_pp (w_p - sum_{u>p} L_up^T x_u),  p = 3..0.
+__global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
+                                                   int npad, int t0,
+                                                   const int *__restrict__ row_ptr,
+                                                   const int *__restrict__ rows,
+                                                   const double *__restrict__ ws_all,
+                                                   double *xc, double *x,
+                                                   const int *__restrict__ col_x,
                                                    const int *done) {
   if (done && *done) return;
   __shared__ double xs[NB];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x;
-  const int k0 = kb * NB;
-  const double *Ld = ws;
-  const double *Et = ws + NB * NB;
+  const int t = t0 + blockIdx.x;
+  const int k0 = t * NB;
+  const int ncb = npad / NB;
+  const double *Ld = ws_all + (size_t)t * kDenseWsPerBlock;
+  const double *Et = Ld + NB * NB;
+  {
+    const int c = tid & 63, q = tid >> 6;
+    const double *colp = L + (size_t)(k0 + c) * ld;
+    double s = 0.0;
+    for (int a = row_ptr[t]; a < row_ptr[t + 1]; ++a) {
+      const int I = rows[a];
+      if (I >= ncb) break;  // the rhs row block closes the list
+      const double *src = colp + I * NB + 16 * q;
+      const double *xi = xc + I * NB + 16 * q;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += src[r] * xi[r];
+    }
+    part[q][c] = s;
+  }
+  __syncthreads();
   if (tid < 64) {
     const int i = tid & 15, q = tid >> 4;
 #pragma unroll
     for (int p = 3; p >= 0; --p) {
       double acc = 0.0;
-      for (int t = p + 1; t < 4; ++t)
+      for (int u = p + 1; u < 4; ++u)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const int row = 16 * t + 4 * q + rr;
+          const int row = 16 * u + 4 * q + rr;
           acc += Ld[(16 * p + i) * NB + row] * xs[row];
         }
       acc += __shfl_xor(acc, 16, 64);
       acc += __shfl_xor(acc, 32, 64);
-      const double wv = L[(size_t)(k0 + 16 * p + i) * ld + npad] - acc;
+      const int c = 16 * p + i;
+      const double below = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+      const double wv = (L[(size_t)(k0 + c) * ld + npad] - below) - acc;
       double px = 0.0;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        const int c = 4 * q + cc;
-        px += Et[p * 256 + i * 16 + c] * __shfl(wv, c, 64);
+        const int c2 = 4 * q + cc;
+        px += Et[p * 256 + i * 16 + c2] * __shfl(wv, c2, 64);
       }
       px += __shfl_xor(px, 16, 64);
       px += __shfl_xor(px, 32, 64);
@@ -319,99 +352,50 @@ __global__ __launch_bounds__(256) void k_chol_back(double *L, int ld, int npad,
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (blockIdx.x == 0 && k0 + tid < n_x) x[k0 + tid] = xs[tid];
-  }
-  if (blockIdx.x == 0) return;
-  __syncthreads();
-  const int cb = cols[blockIdx.x - 1];  // structurally non-zero tile (kb, cb)
-  const int c = cb * NB + (tid & 63), q = tid >> 6;
-  const double *col = L + (size_t)c * ld + k0 + 16 * q;
-  double s = 0.0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s += col[r] * xs[16 * q + r];
-  part[q][tid & 63] = s;
-  __syncthreads();
-  if (tid < 64) {
-    const double tot = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-    L[(size_t)c * ld + npad] -= tot;
+    xc[k0 + tid] = xs[tid];
+    const int xi = col_x[k0 + tid];
+    if (xi >= 0) x[xi] = xs[tid];
   }
 }
 
 }  // namespace
 
-void launch_dense_init(double *L, int npad, int ld, int n_valid,
+void launch_dense_init(double *L, int npad, int ld, const int *col_x,
                        const int *done_flag, hipStream_t s) {
   hipLaunchKernelGGL(k_dense_init, dim3(2048), dim3(256), 0, s, L, npad, ld,
-                     n_valid, done_flag);
+                     col_x, done_flag);
 }
 
-// Ldiag: (npad/64) blocks of kDenseWsPerBlock doubles (L11 + tile inverses).
-//
-// STRUCTURE-AWARE: the reduced camera matrix is block sparse (two poses couple
-// only through landmarks they both see).  `st` holds, per 64-column step k,
-// the list of row tiles that are structurally non-zero in the FACTOR (tile
-// pattern of S closed under symbolic Cholesky fill, computed once on the
-// host); TRSM, the trailing update and the backward strips touch only those
-// tiles.  Zero tiles stay exactly zero in a dense factorisation too, so the
-// result is bit-identical to the dense sweep; a dense pattern degenerates to
-// it.
+// Level-scheduled, structure-aware blocked Cholesky (see ba_dense_sched.h):
+// per level one batched diagonal launch, one batched TRSM launch and one
+// target-centric update launch; then one backward launch per level.
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
-                        int n_x, const int *done, const DenseStructure &st,
-                        hipStream_t s) {
-  const int ncb = npad / NB;
+                        const int *done, const DenseSchedule &sc,
+                        const DenseDev &dd, hipStream_t s) {
   const int row_limit = npad + 16;  // rows that carry data (rhs = row npad)
-  for (int kb = 0; kb < ncb; ++kb) {
-    const int k0 = kb * NB;
-    double *ws = Ldiag + (size_t)kb * kDenseWsPerBlock;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, L, ld, k0, ws,
+  for (int l = 0; l < sc.nlev; ++l) {
+    const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;
+    hipLaunchKernelGGL(k_chol_diag, dim3(nt), dim3(256), 0, s, L, ld, t0, Ldiag,
                        done);
-    const int nr = st.h_row_ptr[kb + 1] - st.h_row_ptr[kb];  // incl. rhs block
-    const int *rows = st.d_rows + st.h_row_ptr[kb];
-    hipLaunchKernelGGL(k_chol_trsm, dim3(nr), dim3(256), 0, s, L, ld, k0,
-                       row_limit, rows, ws, done);
-    if (nr > 1)
-      hipLaunchKernelGGL(k_chol_syrk, dim3(nr, nr - 1), dim3(256), 0, s, L, ld,
-                         k0, ncb, rows, done);
+    const int it0 = sc.item_ptr[l], ni = sc.item_ptr[l + 1] - it0;
+    if (ni > 0)
+      hipLaunchKernelGGL(k_chol_trsm, dim3(ni), dim3(256), 0, s, L, ld,
+                         row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);
+    const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0;
+    if (ng > 0)
+      hipLaunchKernelGGL(k_chol_update, dim3(ng), dim3(256), 0, s, L, ld, tg0,
+                         dd.tgt_I, dd.tgt_J, dd.tgt_src_ptr, dd.src_t, done);
   }
-  for (int kb = ncb - 1; kb >= 0; --kb) {
-    const double *ws = Ldiag + (size_t)kb * kDenseWsPerBlock;
-    const int nc = st.h_col_ptr[kb + 1] - st.h_col_ptr[kb];
-    hipLaunchKernelGGL(k_chol_back, dim3(1 + nc), dim3(256), 0, s, L, ld, npad,
-                       kb, ws, x, n_x, st.d_cols + st.h_col_ptr[kb], done);
-  }
-}
-
-// Tile pattern -> per-step lists.  `nz[I*ncb + J]` (I >= J) marks non-zero
-// 64x64 tiles of the lower triangle; it is closed under fill-in here.
-void build_dense_structure(int ncb, std::vector<uint8_t> &nz,
-                           std::vector<int> &row_ptr, std::vector<int> &rows,
-                           std::vector<int> &col_ptr, std::vector<int> &cols) {
-  row_ptr.assign(ncb + 1, 0);
-  rows.clear();
-  std::vector<int> rk;
-  for (int k = 0; k < ncb; ++k) {
-    rk.clear();
-    for (int I = k + 1; I < ncb; ++I)
-      if (nz[(size_t)I * ncb + k]) rk.push_back(I);
-    for (size_t a = 0; a < rk.size(); ++a)       // symbolic fill
-      for (size_t b = 0; b <= a; ++b) nz[(size_t)rk[a] * ncb + rk[b]] = 1;
-    for (int I : rk) rows.push_back(I);
-    rows.push_back(ncb);                          // the rhs row block
-    row_ptr[k + 1] = (int)rows.size();
-  }
-  col_ptr.assign(ncb + 1, 0);
-  cols.clear();
-  for (int k = 0; k < ncb; ++k) {
-    for (int c = 0; c < k; ++c)
-      if (nz[(size_t)k * ncb + c]) cols.push_back(c);
-    col_ptr[k + 1] = (int)cols.size();
+  for (int l = sc.nlev - 1; l >= 0; --l) {
+    const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;
+    hipLaunchKernelGGL(k_chol_back, dim3(nt), dim3(256), 0, s, L, ld, npad, t0,
+                       dd.row_ptr, dd.rows, Ldiag, dd.xc, x, dd.col_x, done);
   }
 }
 
-void launch_dense_solve(const DevProblem &d, const DenseStructure &st,
-                        hipStream_t s) {
-  dense_factor_solve(d.L, d.npad, d.ld, d.Ldiag, d.x, 6 * d.N, &d.ctrl->done,
-                     st, s);
+void launch_dense_solve(const DevProblem &d, const DenseSchedule &sc,
+                        const DenseDev &dd, hipStream_t s) {
+  dense_factor_solve(d.L, d.npad, d.ld, d.Ldiag, d.x, &d.ctrl->done, sc, dd, s);
 }
 
 }  // namespace ba

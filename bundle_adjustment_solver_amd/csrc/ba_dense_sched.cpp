@@ -1,0 +1,139 @@
+// ba_dense_sched.cpp — see ba_dense_sched.h.  Host-only.
+#include "ba_dense_sched.h"
+
+#include <algorithm>
+#include <tuple>
+
+namespace ba {
+
+void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj_in,
+                          bool natural_order, DenseSchedule &s) {
+  const int n = ncb;
+  s = DenseSchedule();
+  s.ncb = n;
+  std::vector<uint8_t> A(adj_in);
+  auto at = [&](int a, int b) -> uint8_t & { return A[(size_t)a * n + b]; };
+  for (int v = 0; v < n; ++v) at(v, v) = 0;
+  std::vector<uint8_t> alive(n, 1), blocked(n, 0);
+  std::vector<int> deg(n, 0);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b)
+      if (a != b && (at(a, b) || at(b, a))) {
+        at(a, b) = at(b, a) = 1;
+      }
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b) deg[a] += at(a, b);
+  std::vector<std::vector<int>> rows_of(n);
+  s.pos_of_tile.assign(n, -1);
+  s.tile_at_pos.clear();
+  s.lev_ptr.assign(1, 0);
+  int remaining = n, next = 0;
+  std::vector<int> cand, level, nv;
+  while (remaining > 0) {
+    level.clear();
+    if (natural_order) {
+      for (int v = 0; v < n; ++v)
+        if (alive[v]) {
+          level.push_back(v);
+          break;
+        }
+    } else {
+      int mind = n + 1;
+      for (int v = 0; v < n; ++v)
+        if (alive[v]) mind = std::min(mind, deg[v]);
+      const int thr = mind + std::max(1, mind / 4);
+      cand.clear();
+      for (int v = 0; v < n; ++v)
+        if (alive[v] && deg[v] <= thr) cand.push_back(v);
+      std::stable_sort(cand.begin(), cand.end(),
+                       [&](int a, int b) { return deg[a] < deg[b]; });
+      std::fill(blocked.begin(), blocked.end(), 0);
+      for (int v : cand) {
+        if (blocked[v]) continue;
+        level.push_back(v);
+        blocked[v] = 1;
+        for (int u = 0; u < n; ++u)
+          if (alive[u] && at(v, u)) blocked[u] = 1;
+      }
+      std::sort(level.begin(), level.end());
+    }
+    // eliminate the independent set: neighbours become cliques (fill-in)
+    for (int v : level) {
+      nv.clear();
+      for (int u = 0; u < n; ++u)
+        if (alive[u] && u != v && at(v, u)) nv.push_back(u);
+      rows_of[v] = nv;
+      for (size_t a = 0; a < nv.size(); ++a)
+        for (size_t b = a + 1; b < nv.size(); ++b)
+          if (!at(nv[a], nv[b])) {
+            at(nv[a], nv[b]) = at(nv[b], nv[a]) = 1;
+            deg[nv[a]]++;
+            deg[nv[b]]++;
+          }
+    }
+    for (int v : level) {
+      alive[v] = 0;
+      for (int u : rows_of[v]) deg[u]--;
+      s.pos_of_tile[v] = next++;
+      s.tile_at_pos.push_back(v);
+      --remaining;
+    }
+    s.lev_ptr.push_back(next);
+  }
+  s.nlev = (int)s.lev_ptr.size() - 1;
+
+  // rows per position (ascending positions, rhs block last)
+  s.row_ptr.assign(n + 1, 0);
+  s.rows.clear();
+  double nz_tiles = n;
+  for (int p = 0; p < n; ++p) {
+    std::vector<int> r;
+    for (int u : rows_of[s.tile_at_pos[p]]) r.push_back(s.pos_of_tile[u]);
+    std::sort(r.begin(), r.end());
+    nz_tiles += (double)r.size();
+    for (int I : r) s.rows.push_back(I);
+    s.rows.push_back(n);
+    s.row_ptr[p + 1] = (int)s.rows.size();
+    const double m = (double)r.size() + 1.0;  // incl. rhs row block
+    const double c3 = 64.0 * 64.0 * 64.0;
+    s.flops += c3 / 3.0 + m * c3 + m * (m + 1.0) * c3;
+  }
+  s.fill = nz_tiles / ((double)n * (n + 1) / 2.0);
+
+  // work lists per level
+  s.item_ptr.assign(1, 0);
+  s.tgt_ptr.assign(1, 0);
+  s.tgt_src_ptr.clear();
+  std::vector<std::tuple<int, int, int>> trip;
+  for (int l = 0; l < s.nlev; ++l) {
+    trip.clear();
+    for (int p = s.lev_ptr[l]; p < s.lev_ptr[l + 1]; ++p) {
+      const int b = s.row_ptr[p], e = s.row_ptr[p + 1];
+      for (int a = b; a < e; ++a) {
+        s.item_t.push_back(p);
+        s.item_I.push_back(s.rows[a]);
+        for (int c = b; c <= a; ++c)
+          if (s.rows[c] < n) trip.emplace_back(s.rows[a], s.rows[c], p);
+      }
+    }
+    s.item_ptr.push_back((int)s.item_t.size());
+    // target-centric: every (I,J) tile touched in this level, with the panels
+    // that update it in ascending position order
+    std::sort(trip.begin(), trip.end());
+    for (size_t k = 0; k < trip.size(); ++k) {
+      const bool is_new = k == 0 ||
+                          std::get<0>(trip[k]) != std::get<0>(trip[k - 1]) ||
+                          std::get<1>(trip[k]) != std::get<1>(trip[k - 1]);
+      if (is_new) {
+        s.tgt_I.push_back(std::get<0>(trip[k]));
+        s.tgt_J.push_back(std::get<1>(trip[k]));
+        s.tgt_src_ptr.push_back((int)s.src_t.size());
+      }
+      s.src_t.push_back(std::get<2>(trip[k]));
+    }
+    s.tgt_ptr.push_back((int)s.tgt_I.size());
+  }
+  s.tgt_src_ptr.push_back((int)s.src_t.size());
+}
+
+}  // namespace ba

@@ -1,0 +1,53 @@
+// ba_dense_sched.h — host-side symbolic analysis for the structure-aware,
+// level-scheduled Cholesky of the reduced camera system (ba_dense.hip).
+//
+// The reference solves the reduced camera system with a dense, sequential,
+// unblocked LDLT (reference core/full_bundle_adjustment_solver.cpp:905).  The
+// matrix is block sparse: two poses couple only through landmarks they both
+// observe.  Here the 6x6 pose blocks are grouped into 64-column TILES
+// (kPosesPerTile poses + padding); on the tile graph we compute
+//   1. a parallel minimum-degree ordering: each LEVEL is an independent set of
+//      low-degree tiles (for a band matrix this is odd-even cyclic reduction,
+//      log2(n) levels; for a dense matrix it degenerates to one tile per level,
+//      i.e. the classic right-looking sweep);
+//   2. the symbolic factor (fill-in) under that ordering;
+//   3. static work lists per level: diagonal tiles, TRSM items, and update
+//      TARGETS with their source panels (target-centric so that tiles shared by
+//      several panels of one level are summed by one workgroup in fixed order:
+//      deterministic, no atomics).
+// Skipping structurally zero tiles is exact (they are zero in a dense
+// factorisation too); only the floating-point summation order differs from the
+// natural ordering.
+#ifndef BA_DENSE_SCHED_H_
+#define BA_DENSE_SCHED_H_
+
+#include <cstdint>
+#include <vector>
+
+namespace ba {
+
+constexpr int kPosesPerTile = 10;  // 60 columns + 4 padding columns per tile
+
+struct DenseSchedule {
+  int ncb = 0;    // tiles (the rhs row block has index ncb)
+  int nlev = 0;
+  std::vector<int> pos_of_tile;  // original tile/group -> elimination position
+  std::vector<int> tile_at_pos;  // inverse
+  std::vector<int> lev_ptr;      // nlev+1: positions [lev_ptr[l], lev_ptr[l+1])
+  std::vector<int> row_ptr, rows;  // per position: non-zero row tiles below
+                                   // (ascending positions), rhs block last
+  std::vector<int> item_ptr, item_t, item_I;        // TRSM items per level
+  std::vector<int> tgt_ptr, tgt_I, tgt_J;           // update targets per level
+  std::vector<int> tgt_src_ptr, src_t;              // sources of each target
+  double fill = 1.0;        // non-zero factor tiles / all lower tiles
+  double flops = 0.0;       // executed flops of factor + solves (estimate)
+};
+
+// `adj` is the symmetric ncb x ncb tile adjacency (non-zero off-diagonal
+// tiles), row-major bytes.  `natural_order` = keep the given order and put
+// every tile in its own level (debug / dense comparison).
+void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj,
+                          bool natural_order, DenseSchedule &s);
+
+}  // namespace ba
+#endif

@@ -98,6 +98,8 @@ struct DevProblem {
   double *L;
   int npad, ld;
   double *Ldiag;   // (npad/64) * kDenseWsPerBlock (diagonal factors + inverses)
+  int *pose_col;   // N: first dense column of optimised pose j
+  int *col_x;      // npad: dense column -> 6*pose + r, or -1 (padding)
 };
 
 constexpr int kCostGrid = 1024;
@@ -118,25 +120,25 @@ void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s);
 
 // ---- dense solver (ba_dense.hip) ----
 // Factor the npad x npad lower matrix in d.L (with the rhs carried as row
-// `npad`) and write x (first 6N entries).
-// Per-step lists of structurally non-zero 64x64 tiles of the factor (host
-// copies of the CSR pointers for grid sizes, device copies of the lists).
-struct DenseStructure {
-  std::vector<int> h_row_ptr, h_col_ptr;  // ncb+1 each
-  int *d_rows = nullptr;                  // row tiles per step (+ rhs block)
-  int *d_cols = nullptr;                  // column tiles per backward step
-  double fill = 1.0;                      // non-zero tiles / all lower tiles
+// `npad`) and write x (6N entries, pose order).
+// Device copies of the static work lists of the level-scheduled Cholesky
+// (host side: DenseSchedule in ba_dense_sched.h).
+struct DenseDev {
+  int *row_ptr = nullptr, *rows = nullptr;       // per position
+  int *item_t = nullptr, *item_I = nullptr;      // TRSM items
+  int *tgt_I = nullptr, *tgt_J = nullptr;        // update targets
+  int *tgt_src_ptr = nullptr, *src_t = nullptr;  // their source panels
+  int *col_x = nullptr;   // npad: column -> index into x (6*pose + r) or -1
+  double *xc = nullptr;   // npad: solution in column order
 };
-void build_dense_structure(int ncb, std::vector<uint8_t> &nz,
-                           std::vector<int> &row_ptr, std::vector<int> &rows,
-                           std::vector<int> &col_ptr, std::vector<int> &cols);
-void launch_dense_solve(const DevProblem &d, const DenseStructure &st,
-                        hipStream_t s);
-// stand-alone helper for ba_dense_spd_solve
+struct DenseSchedule;
+void launch_dense_solve(const DevProblem &d, const DenseSchedule &sc,
+                        const DenseDev &dd, hipStream_t s);
+// stand-alone form for ba_dense_spd_solve (x receives n_x entries via col_x)
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
-                        int n_x, const int *done_flag,
-                        const DenseStructure &st, hipStream_t s);
-void launch_dense_init(double *L, int npad, int ld, int n_valid,
+                        const int *done_flag, const DenseSchedule &sc,
+                        const DenseDev &dd, hipStream_t s);
+void launch_dense_init(double *L, int npad, int ld, const int *col_x,
                        const int *done_flag, hipStream_t s);
 
 // ---- pose-only (ba_pose_only.hip) ----

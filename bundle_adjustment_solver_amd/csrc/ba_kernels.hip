@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
   double bc = 0.0;
   for (int ch = d.pose_rchunk_ptr[j]; ch < d.pose_rchunk_ptr[j + 1]; ++ch)
     bc += d.rpart[(size_t)ch * 6 + r];
-  d.L[(size_t)(6 * j + r) * d.ld + d.npad] = d.a[(size_t)j * 6 + r] - bc;
+  d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = d.a[(size_t)j * 6 + r] - bc;
 }
 
 // partial sums of BCinvBt_jk over a chunk of the (j,k) block's triples:
@@ -473,8 +473,18 @@ __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
   for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
     s += d.spart[(size_t)ch * 36 + e];
   const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
-  // element (row 6k+c, col 6j+r) of the lower triangle holds S_jk[r][c]
-  d.L[(size_t)(6 * j + r) * d.ld + (6 * k + c)] = val;
+  // S_jk[r][c] lives at dense (row, col) = (col_of(k)+c, col_of(j)+r) or its
+  // transpose, whichever is in the LOWER triangle under the tile ordering
+  int row = d.pose_col[k] + c, col = d.pose_col[j] + r;
+  // diagonal block: entries (r,c) and (c,r) differ in the last bits (V W^T is
+  // not bitwise symmetric) -> only the lower one is stored, never both
+  if (j == k && row < col) return;
+  if (row < col) {
+    const int t = row;
+    row = col;
+    col = t;
+  }
+  d.L[(size_t)col * d.ld + row] = val;
 }
 
 // y_i, trial point, landmark-side model terms and |y_i|
@@ -727,7 +737,7 @@ void launch_linearize(const DevProblem &d, hipStream_t s) {
 }
 
 void launch_schur(const DevProblem &d, hipStream_t s) {
-  launch_dense_init(d.L, d.npad, d.ld, 6 * d.N, &d.ctrl->done, s);
+  launch_dense_init(d.L, d.npad, d.ld, d.col_x, &d.ctrl->done, s);
   if (d.P > 0)
     hipLaunchKernelGGL(k_pair_bcinv, dim3(cdiv(d.P, kBlock)), dim3(kBlock), 0,
                        s, d);

@@ -1,6 +1,8 @@
 // ba_plan.cpp — see ba_plan.h.  Host-only, no HIP.
 #include "ba_plan.h"
 
+#include "ba_dense_sched.h"
+
 #include <algorithm>
 #include <numeric>
 
@@ -322,19 +324,15 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
 
   // ---- tile pattern of S (global: every shard factors the same matrix) ----
   {
-    const int n6 = 6 * N;
-    pl.ncb = std::max(1, (n6 + kDenseTile - 1) / kDenseTile);
+    // tiles = groups of kPosesPerTile consecutive optimised poses
+    pl.ncb = std::max(1, (N + kPosesPerTile - 1) / kPosesPerTile);
     const int ncb = pl.ncb;
     pl.tile_nz.assign((size_t)ncb * ncb, 0);
     for (int t = 0; t < ncb; ++t) pl.tile_nz[(size_t)t * ncb + t] = 1;
-    auto mark = [&](int j, int k) {  // optimised poses j <= k are coupled
-      const int a0 = (6 * j) / kDenseTile, a1 = (6 * j + 5) / kDenseTile;
-      const int b0 = (6 * k) / kDenseTile, b1 = (6 * k + 5) / kDenseTile;
-      for (int a = a0; a <= a1; ++a)
-        for (int b = b0; b <= b1; ++b) {
-          const int I = std::max(a, b), J = std::min(a, b);
-          pl.tile_nz[(size_t)I * ncb + J] = 1;
-        }
+    auto mark = [&](int j, int k) {  // optimised poses j, k are coupled
+      const int a = j / kPosesPerTile, b = k / kPosesPerTile;
+      pl.tile_nz[(size_t)a * ncb + b] = 1;
+      pl.tile_nz[(size_t)b * ncb + a] = 1;
     };
     if (in.world == 1) {
       for (int64_t bk = 0; bk < pl.B; ++bk) mark(pl.sblk_j[bk], pl.sblk_k[bk]);

@@ -37,7 +37,6 @@ struct PlanInput {
 constexpr int kPoseChunk = 1024;   // observations per A/a partial-sum item
 constexpr int kRhsChunk = 1024;    // pairs per rhs partial-sum item
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
-constexpr int kDenseTile = 64;     // column-block width of the dense solver
 
 struct Plan {
   // ---- sizes ----
@@ -93,8 +92,8 @@ struct Plan {
   std::vector<int64_t> tchunk_begin, tchunk_end;
   std::vector<int32_t> sblk_tchunk_ptr;  // B+1
   // ---- tile pattern of the GLOBAL reduced camera matrix (all shards) ----
-  int ncb = 0;                           // number of 64-column blocks
-  std::vector<uint8_t> tile_nz;          // ncb*ncb, [I*ncb+J], I >= J
+  int ncb = 0;                           // tiles = groups of kPosesPerTile poses
+  std::vector<uint8_t> tile_nz;          // ncb*ncb symmetric adjacency
 };
 
 // Owner rank of every point: locality order (first observing optimised pose,

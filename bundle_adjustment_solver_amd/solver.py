@@ -421,6 +421,13 @@ class BaProblem:
         check(self.lib.ba_get_xy(self.h, _dp(x), _dp(y)), "ba_get_xy")
         return x, y
 
+    def get_dense_info(self):
+        out = np.zeros(4)
+        check(self.lib.ba_get_dense_info(self.h, _dp(out)),
+              "ba_get_dense_info")
+        return dict(fill=out[0], flops=out[1], levels=int(out[2]),
+                    npad=int(out[3]))
+
     def dense_spd_solve(self, A, b):
         A = np.ascontiguousarray(A, np.float64)
         b = np.ascontiguousarray(b, np.float64)

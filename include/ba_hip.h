@@ -65,8 +65,9 @@ typedef struct {
 int ba_create(ba_handle **out, int device_id);
 void ba_destroy(ba_handle *h);
 const char *ba_last_error(void);
-/* Run all kernels of this handle on the given hipStream_t (NULL = the
- * handle's own stream). */
+/* Run all kernels of this handle on the given hipStream_t (used as is: NULL
+ * is HIP's default stream).  Without this call the handle uses a stream of
+ * its own. */
 int ba_set_stream(ba_handle *h, void *hip_stream);
 
 /* ---- problem construction (host arrays, copied) ------------------------ */
@@ -168,6 +169,12 @@ int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18);
 /* reduced camera system, (6N)^2 row-major, and rhs, in opt-pose order */
 int ba_get_S(ba_handle *h, double *S, double *rhs);
 int ba_get_xy(ba_handle *h, double *x6, double *y3);
+
+/* Structure of the reduced-system factorisation chosen at ba_finalize:
+ * out4 = { non-zero tile fraction of the factor (1 = dense), executed flop
+ * estimate per solve, number of elimination levels (launch depth), padded
+ * matrix order }. */
+int ba_get_dense_info(ba_handle *h, double out4[4]);
 
 /* ---- dense SPD solve alone (tests / micro-bench of the MFMA kernel) ---- */
 /* Solves A x = b for symmetric positive (semi-)definite A (n x n row-major

@@ -258,13 +258,16 @@ def test_dense_spd_solve(built):
 
 def test_reproducible_bits(built):
     """No floating-point atomics: two runs give bit-identical results."""
-    sc = small_scene("stereo")
-    pr = scenes.scaled_problem(sc)
-    outs = []
-    for _ in range(2):
-        g = make_gpu(pr)
-        g.solve(O.make_options(max_iter=6, thr_step=0, thr_cost=0,
-                               cls=BaOptions))
-        outs.append((g.get_poses().copy(), g.get_points()[0].copy()))
-    assert (outs[0][0] == outs[1][0]).all()
-    assert (outs[0][1] == outs[1][1]).all()
+    for kind in ("stereo", "c1"):
+        pr = scenes.scaled_problem(small_scene(kind))
+        outs = []
+        for _ in range(3):
+            g = make_gpu(pr)
+            rows, _ = g.solve(O.make_options(max_iter=14, thr_step=0,
+                                             thr_cost=0, cls=BaOptions))
+            outs.append((g.get_poses().copy(), g.get_points()[0].copy(),
+                         [r.trial_cost for r in rows]))
+        for o in outs[1:]:
+            assert (outs[0][0] == o[0]).all()
+            assert (outs[0][1] == o[1]).all()
+            assert outs[0][2] == o[2]
