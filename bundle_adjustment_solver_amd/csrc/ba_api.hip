@@ -383,13 +383,19 @@ int ba_finalize(ba_handle *h) {
       h->upload(&d.sblk_k, pl.sblk_k) || h->upload(&d.tri_p, pl.tri_p) ||
       h->upload(&d.tri_q, pl.tri_q) || h->upload(&d.tchunk_blk, pl.tchunk_blk) ||
       h->upload(&d.tchunk_begin, pl.tchunk_begin) || h->upload(&d.tchunk_end, pl.tchunk_end) ||
-      h->upload(&d.sblk_tchunk_ptr, pl.sblk_tchunk_ptr))
+      h->upload(&d.sblk_tchunk_ptr, pl.sblk_tchunk_ptr) ||
+      h->upload(&d.swg_lm_begin, pl.swg_lm_begin) || h->upload(&d.swg_slot_ptr, pl.swg_slot_ptr) ||
+      h->upload(&d.slot_tri_ptr, pl.slot_tri_ptr) || h->upload(&d.ltri, pl.ltri) ||
+      h->upload(&d.blk_contrib_ptr, pl.blk_contrib_ptr) || h->upload(&d.contrib_slot, pl.contrib_slot))
     return -1;
+  d.n_swg = (int)pl.swg_lm_begin.size() - 1;
+  d.n_slot = (int)pl.slot_blk.size();
+  if (h->dalloc(&d.spart2, (size_t)d.n_slot * 36)) return -1;
 
   // per-iteration storage
   if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.b, (size_t)pl.M * 3) ||
       h->dalloc(&d.Cinv, (size_t)pl.M * 6) || h->dalloc(&d.Cinvb, (size_t)pl.M * 3) ||
-      h->dalloc(&d.W, (size_t)pl.P * 18) || h->dalloc(&d.V, (size_t)pl.P * 18) ||
+      h->dalloc(&d.W, (size_t)pl.P * 18) ||
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) || h->dalloc(&d.A, (size_t)pl.N * 36) ||
       h->dalloc(&d.a, (size_t)pl.N * 6) || h->dalloc(&d.rpart, (size_t)d.n_rchunk * 6) ||
       h->dalloc(&d.spart, (size_t)d.n_tchunk * 36) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
@@ -398,7 +404,6 @@ int ba_finalize(ba_handle *h) {
       h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
     return -1;
   HIP_TRY(hipMemset(d.W, 0, std::max<size_t>(1, (size_t)pl.P * 18) * sizeof(double)));
-  HIP_TRY(hipMemset(d.V, 0, std::max<size_t>(1, (size_t)pl.P * 18) * sizeof(double)));
   HIP_TRY(hipMemset(d.x, 0, ((size_t)pl.N * 6 + 64) * sizeof(double)));
   HIP_TRY(hipMemset(d.y, 0, std::max<size_t>(1, (size_t)pl.M * 3) * sizeof(double)));
   HIP_TRY(hipMemset(d.cost_part, 0, ba::kCostGrid * sizeof(double)));

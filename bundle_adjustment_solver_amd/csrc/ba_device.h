@@ -71,13 +71,20 @@ struct DevProblem {
   int32_t *tchunk_blk;
   int64_t *tchunk_begin, *tchunk_end;
   int32_t *sblk_tchunk_ptr;
+  // Schur workgroups (landmark-major, LDS slots)
+  int n_swg, n_slot;
+  int32_t *swg_lm_begin, *swg_slot_ptr;
+  int64_t *slot_tri_ptr;
+  uint32_t *ltri;
+  int64_t *blk_contrib_ptr;
+  int32_t *contrib_slot;
+  double *spart2;  // n_slot*36 slot partial sums
   // per-iteration blocks
   double *Cd;      // M*6   damped C_i upper (00 01 02 11 12 22)
   double *b;       // M*3
   double *Cinv;    // M*6   symmetric inverse upper
   double *Cinvb;   // M*3
   double *W;       // P*18  B_ji 6x3 row-major
-  double *V;       // P*18  B_ji Cinv_i
   double *Apart;   // n_achunk*27
   double *A;       // N*36  damped, full
   double *a;       // N*6

@@ -5,9 +5,9 @@
 //   k_lin_landmarks        :716-831 (landmark side: C_i, b_i, W_ji)
 //                          + :846-856 (damp, 3x3 LDLT pseudo-inverse, Cinv b)
 //   k_lin_poses/_finalize  :716-810 (pose side: A_j, a_j) + :833-844 (damp)
-//   k_pair_bcinv           :862      V_ji = W_ji Cinv_i
-//   k_rhs_partial          :864,:887 rhs_j = a_j - sum_i V_ji b_i
-//   k_schur_partial/_final :866-885  S_jk = d_jk A_j - sum_i V_ji W_ki^T
+//   k_rhs_partial/_final   :864,:887 rhs_j = a_j - sum_i B_ji (Cinv_i b_i)
+//   k_schur_lds/_partial/_final :859-885  S_jk = d_jk A_j - sum_i V_ji W_ki^T,
+//                          V_ji = W_ji Cinv_i formed in LDS, never stored
 //   k_backsub_update       :910-917 (y_i), :495-499 (X += y), :442-452 model
 //   k_pose_update          :487-494 (exp(x) T), :437-441 model, :962 |x|
 //   k_scalars / k_control  :928-1007 trust region, convergence, log
@@ -342,27 +342,8 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   }
 }
 
-// V_ji = W_ji Cinv_i   (reference :862)
-__global__ __launch_bounds__(kBlock) void k_pair_bcinv(DevProblem d) {
-  if (d.ctrl->done) return;
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= d.P) return;
-  const int i = d.pair_lm[p];
-  const double *ci = d.Cinv + (size_t)i * 6;
-  const double i00 = ci[0], i01 = ci[1], i02 = ci[2], i11 = ci[3], i12 = ci[4],
-               i22 = ci[5];
-  const double *Wp = d.W + (size_t)p * 18;
-  double *Vp = d.V + (size_t)p * 18;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const double w0 = Wp[r * 3 + 0], w1 = Wp[r * 3 + 1], w2 = Wp[r * 3 + 2];
-    Vp[r * 3 + 0] = w0 * i00 + w1 * i01 + w2 * i02;
-    Vp[r * 3 + 1] = w0 * i01 + w1 * i11 + w2 * i12;
-    Vp[r * 3 + 2] = w0 * i02 + w1 * i12 + w2 * i22;
-  }
-}
-
-// partial sums of BCinv_b_j = sum_i V_ji b_i over a chunk of pose j's pairs
+// partial sums of BCinv_b_j = sum_i B_ji (Cinv_i b_i) over a chunk of pose j's
+// pairs (reference :864; B Cinv is never materialised: (B Cinv) b = B (Cinv b))
 __global__ __launch_bounds__(kBlock) void k_rhs_partial(DevProblem d) {
   if (d.ctrl->done) return;
   __shared__ double sm[4];
@@ -372,12 +353,12 @@ __global__ __launch_bounds__(kBlock) void k_rhs_partial(DevProblem d) {
   for (int64_t s = d.rchunk_begin[ch] + threadIdx.x; s < e; s += kBlock) {
     const int64_t p = d.ppair[s];
     const int i = d.pair_lm[p];
-    const double *Vp = d.V + (size_t)p * 18;
-    const double *bi = d.b + (size_t)i * 3;
-    const double b0 = bi[0], b1 = bi[1], b2 = bi[2];
+    const double *Wp = d.W + (size_t)p * 18;
+    const double *cb = d.Cinvb + (size_t)i * 3;
+    const double b0 = cb[0], b1 = cb[1], b2 = cb[2];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
-      acc[r] += Vp[r * 3 + 0] * b0 + Vp[r * 3 + 1] * b1 + Vp[r * 3 + 2] * b2;
+      acc[r] += Wp[r * 3 + 0] * b0 + Wp[r * 3 + 1] * b1 + Wp[r * 3 + 2] * b2;
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -426,8 +407,54 @@ __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
   d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = d.a[(size_t)j * 6 + r] - bc;
 }
 
-// partial sums of BCinvBt_jk over a chunk of the (j,k) block's triples:
-// one wave per chunk (reference :866-870)
+// Landmark-major Schur complement (reference :859-872): one workgroup per run
+// of consecutive landmarks.  W_ji and V_ji = W_ji Cinv_i of the run are staged
+// in LDS once (W is read from HBM exactly once), then the 36 entries of every
+// workgroup-local block slot are accumulated by 36 threads over the slot's
+// triple list in landmark order.  Slots of one block are summed across
+// workgroups by k_schur_final in workgroup order: deterministic, no atomics.
+__global__ __launch_bounds__(kBlock) void k_schur_lds(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ double Ws[kSchurPairs * 18];
+  __shared__ double Vs[kSchurPairs * 18];
+  const int wg = blockIdx.x;
+  const int s0 = d.swg_slot_ptr[wg], s1 = d.swg_slot_ptr[wg + 1];
+  if (s0 == s1) return;  // empty (big landmark handled by the triple list)
+  const int l0 = d.swg_lm_begin[wg], l1 = d.swg_lm_begin[wg + 1];
+  const int64_t p0 = d.lm_pair_ptr[l0];
+  const int np = (int)(d.lm_pair_ptr[l1] - p0);
+  // stage: one thread per (pair, row)
+  for (int t = threadIdx.x; t < np * 6; t += kBlock) {
+    const int lp = t / 6, r = t - lp * 6;
+    const double *Wp = d.W + (size_t)(p0 + lp) * 18 + r * 3;
+    const double w0 = Wp[0], w1 = Wp[1], w2 = Wp[2];
+    const double *ci = d.Cinv + (size_t)d.pair_lm[p0 + lp] * 6;
+    Ws[lp * 18 + r * 3 + 0] = w0;
+    Ws[lp * 18 + r * 3 + 1] = w1;
+    Ws[lp * 18 + r * 3 + 2] = w2;
+    Vs[lp * 18 + r * 3 + 0] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
+    Vs[lp * 18 + r * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
+    Vs[lp * 18 + r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+  }
+  __syncthreads();
+  const int g = threadIdx.x / 36, e = threadIdx.x - g * 36;
+  if (g >= 7) return;
+  const int r = e / 6, c = e - r * 6;
+  for (int s = s0 + g; s < s1; s += 7) {
+    double acc = 0.0;
+    const int64_t t1 = d.slot_tri_ptr[s + 1];
+    for (int64_t t = d.slot_tri_ptr[s]; t < t1; ++t) {
+      const uint32_t pq = d.ltri[t];
+      const double *v = Vs + (pq >> 16) * 18 + r * 3;
+      const double *w = Ws + (pq & 0xffffu) * 18 + c * 3;
+      acc += v[0] * w[0] + v[1] * w[1] + v[2] * w[2];
+    }
+    d.spart2[(size_t)s * 36 + e] = acc;
+  }
+}
+
+// Same sums for landmarks seen by more than kSchurPairs poses: one wave per
+// chunk of the block's global triple list, V computed on the fly.
 __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
   if (d.ctrl->done) return;
   const int ch = blockIdx.x;
@@ -436,14 +463,20 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
   const int64_t e = d.tchunk_end[ch];
   for (int64_t t = d.tchunk_begin[ch] + threadIdx.x; t < e; t += 64) {
-    const double *Vp = d.V + (size_t)d.tri_p[t] * 18;
+    const int64_t p = d.tri_p[t];
+    const double *Wp = d.W + (size_t)p * 18;
     const double *Wq = d.W + (size_t)d.tri_q[t] * 18;
+    const double *ci = d.Cinv + (size_t)d.pair_lm[p] * 6;
     double v[18], w[18];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      v[k] = Vp[k];
-      w[k] = Wq[k];
+    for (int r = 0; r < 6; ++r) {
+      const double w0 = Wp[r * 3 + 0], w1 = Wp[r * 3 + 1], w2 = Wp[r * 3 + 2];
+      v[r * 3 + 0] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
+      v[r * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
+      v[r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
     }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) w[k] = Wq[k];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -470,6 +503,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
   const int r = e / 6, c = e % 6;
   const int j = d.sblk_j[blk], k = d.sblk_k[blk];
   double s = 0.0;
+  for (int64_t q = d.blk_contrib_ptr[blk]; q < d.blk_contrib_ptr[blk + 1]; ++q)
+    s += d.spart2[(size_t)d.contrib_slot[q] * 36 + e];
   for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
     s += d.spart[(size_t)ch * 36 + e];
   const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
@@ -480,14 +515,17 @@ __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
   // not bitwise symmetric) -> only the lower one is stored, never both
   if (j == k && row < col) return;
   if (row < col) {
-    const int t = row;
+    const int t2 = row;
     row = col;
-    col = t;
+    col = t2;
   }
   d.L[(size_t)col * d.ld + row] = val;
 }
 
-// y_i, trial point, landmark-side model terms and |y_i|
+// y_i, trial point, landmark-side model terms and |y_i|.
+// y_i = Cinv_i b_i - Cinv_i (sum_j B_ji^T x_j)  (reference :910-917; CinvBt is
+// never materialised) — the same vector sum_j B_ji^T x_j is the cross term of
+// the quadratic model (reference :447-452), so W is read once.
 __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
   if (d.ctrl->done) return;
   __shared__ double sm[4];
@@ -497,28 +535,25 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
   double est = 0.0, nrm = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.M;
        i += gridDim.x * kBlock) {
-    double av0 = 0, av1 = 0, av2 = 0;  // sum_j V_ji^T x_j
     double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
     for (int64_t p = d.lm_pair_ptr[i]; p < d.lm_pair_ptr[i + 1]; ++p) {
       const double *xj = d.x + (size_t)d.pair_pose[p] * 6;
-      const double *Vp = d.V + (size_t)p * 18;
       const double *Wp = d.W + (size_t)p * 18;
-      double s0 = 0, s1 = 0, s2 = 0, u0 = 0, u1 = 0, u2 = 0;
+      double u0 = 0, u1 = 0, u2 = 0;
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const double xr = xj[r];
-        s0 += Vp[r * 3 + 0] * xr;
-        s1 += Vp[r * 3 + 1] * xr;
-        s2 += Vp[r * 3 + 2] * xr;
         u0 += Wp[r * 3 + 0] * xr;
         u1 += Wp[r * 3 + 1] * xr;
         u2 += Wp[r * 3 + 2] * xr;
       }
-      av0 += s0; av1 += s1; av2 += s2;
       bx0 += u0; bx1 += u1; bx2 += u2;
     }
+    const double *ci = d.Cinv + (size_t)i * 6;
     const double *cb = d.Cinvb + (size_t)i * 3;
-    const double y0 = cb[0] - av0, y1 = cb[1] - av1, y2 = cb[2] - av2;
+    const double y0 = cb[0] - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);
+    const double y1 = cb[1] - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);
+    const double y2 = cb[2] - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);
     double *yo = d.y + (size_t)i * 3;
     yo[0] = y0; yo[1] = y1; yo[2] = y2;
     const double *Xi = Xc + (size_t)i * 3;
@@ -738,14 +773,13 @@ void launch_linearize(const DevProblem &d, hipStream_t s) {
 
 void launch_schur(const DevProblem &d, hipStream_t s) {
   launch_dense_init(d.L, d.npad, d.ld, d.col_x, &d.ctrl->done, s);
-  if (d.P > 0)
-    hipLaunchKernelGGL(k_pair_bcinv, dim3(cdiv(d.P, kBlock)), dim3(kBlock), 0,
-                       s, d);
   if (d.n_rchunk > 0)
     hipLaunchKernelGGL(k_rhs_partial, dim3(d.n_rchunk), dim3(kBlock), 0, s, d);
   if (d.N > 0)
     hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)),
                        dim3(kBlock), 0, s, d);
+  if (d.n_swg > 0)
+    hipLaunchKernelGGL(k_schur_lds, dim3(d.n_swg), dim3(kBlock), 0, s, d);
   if (d.n_tchunk > 0)
     hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
   if (d.B > 0)

@@ -255,71 +255,142 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
                 pl.rchunk_end, pl.pose_rchunk_ptr);
   }
 
-  // ---- Schur triples sorted by (j, k, landmark) ----
+  // ---- Schur complement structure ----
+  // Non-zero upper blocks (j <= k) of S = union over landmarks of J(i) x J(i),
+  // plus every diagonal.  Landmarks are processed LANDMARK-MAJOR by "Schur
+  // workgroups": a workgroup stages the W blocks of a run of consecutive
+  // landmarks (<= kSchurPairs pairs) in LDS and accumulates their
+  // contributions into workgroup-local block SLOTS; a second kernel sums the
+  // slots of each block in workgroup order (deterministic).  Landmarks seen by
+  // more than kSchurPairs poses go through the global (j,k)-sorted triple list.
   {
-    int64_t T = 0;
-    for (int i = 0; i < M; ++i) {
-      const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
-      T += d * (d + 1) / 2;
-    }
-    pl.T = T;
-    std::vector<int64_t> tp(T), tq(T);
-    {
-      int64_t t = 0;
-      for (int i = 0; i < M; ++i)
-        for (int64_t p = pl.lm_pair_ptr[i]; p < pl.lm_pair_ptr[i + 1]; ++p)
-          for (int64_t q = p; q < pl.lm_pair_ptr[i + 1]; ++q) {
-            tp[t] = p;
-            tq[t] = q;
-            ++t;
-          }
-    }
-    // LSD radix: stable counting sort by k, then by j
-    std::vector<int64_t> tp2(T), tq2(T);
-    auto pass = [&](bool by_q, std::vector<int64_t> &sp,
-                    std::vector<int64_t> &sq, std::vector<int64_t> &dp,
-                    std::vector<int64_t> &dq) {
-      std::vector<int64_t> cntv(N + 1, 0);
-      for (int64_t t = 0; t < T; ++t)
-        cntv[pl.pair_pose[by_q ? sq[t] : sp[t]] + 1]++;
-      for (int j = 0; j < N; ++j) cntv[j + 1] += cntv[j];
-      for (int64_t t = 0; t < T; ++t) {
-        const int64_t d = cntv[pl.pair_pose[by_q ? sq[t] : sp[t]]]++;
-        dp[d] = sp[t];
-        dq[d] = sq[t];
+    // block set as a CSR over pose rows
+    std::vector<std::vector<int32_t>> rowk(N);
+    for (int j = 0; j < N; ++j) rowk[j].push_back(j);
+    for (int i = 0; i < M; ++i)
+      for (int64_t p = pl.lm_pair_ptr[i]; p < pl.lm_pair_ptr[i + 1]; ++p) {
+        auto &rk = rowk[pl.pair_pose[p]];
+        for (int64_t q = p; q < pl.lm_pair_ptr[i + 1]; ++q) {
+          const int32_t k = pl.pair_pose[q];
+          if (rk.empty() || rk.back() != k) rk.push_back(k);
+        }
       }
-    };
-    pass(true, tp, tq, tp2, tq2);
-    pass(false, tp2, tq2, tp, tq);
-    pl.tri_p.swap(tp);
-    pl.tri_q.swap(tq);
-    // blocks (every diagonal present, even without triples)
+    std::vector<int64_t> blk_row_ptr(N + 1, 0);
     pl.sblk_j.clear();
     pl.sblk_k.clear();
-    pl.sblk_tri_ptr.clear();
-    int64_t t = 0;
     for (int j = 0; j < N; ++j) {
-      bool have_diag = false;
-      while (t < T && pl.pair_pose[pl.tri_p[t]] == j) {
-        const int k = pl.pair_pose[pl.tri_q[t]];
-        have_diag = true;
+      auto &rk = rowk[j];
+      std::sort(rk.begin(), rk.end());
+      rk.erase(std::unique(rk.begin(), rk.end()), rk.end());
+      for (int32_t k : rk) {
         pl.sblk_j.push_back(j);
         pl.sblk_k.push_back(k);
-        pl.sblk_tri_ptr.push_back(t);
-        while (t < T && pl.pair_pose[pl.tri_p[t]] == j &&
-               pl.pair_pose[pl.tri_q[t]] == k)
-          ++t;
       }
-      if (!have_diag) {
-        pl.sblk_j.push_back(j);
-        pl.sblk_k.push_back(j);
-        pl.sblk_tri_ptr.push_back(t);
-      }
+      blk_row_ptr[j + 1] = (int64_t)pl.sblk_j.size();
     }
-    pl.sblk_tri_ptr.push_back(T);
     pl.B = (int64_t)pl.sblk_j.size();
-    make_chunks(pl.sblk_tri_ptr, (int)pl.B, kTriChunk, pl.tchunk_blk,
-                pl.tchunk_begin, pl.tchunk_end, pl.sblk_tchunk_ptr);
+    auto block_of = [&](int32_t j, int32_t k) -> int32_t {
+      const int32_t *b0 = &pl.sblk_k[blk_row_ptr[j]];
+      const int32_t *e0 = &pl.sblk_k[blk_row_ptr[j + 1]];
+      return (int32_t)(std::lower_bound(b0, e0, k) - &pl.sblk_k[0]);
+    };
+
+    // (a) big landmarks -> global triple list sorted by (block, landmark)
+    int64_t Tbig = 0, Tall = 0;
+    for (int i = 0; i < M; ++i) {
+      const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
+      Tall += d * (d + 1) / 2;
+      if (d > kSchurPairs) Tbig += d * (d + 1) / 2;
+    }
+    pl.T = Tall;
+    {
+      std::vector<std::pair<int32_t, std::pair<int64_t, int64_t>>> big;
+      big.reserve(Tbig);
+      for (int i = 0; i < M; ++i) {
+        const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
+        if (p1 - p0 <= kSchurPairs) continue;
+        for (int64_t p = p0; p < p1; ++p)
+          for (int64_t q = p; q < p1; ++q)
+            big.push_back({block_of(pl.pair_pose[p], pl.pair_pose[q]), {p, q}});
+      }
+      std::stable_sort(big.begin(), big.end(),
+                       [](const auto &x, const auto &y) { return x.first < y.first; });
+      pl.tri_p.resize(big.size());
+      pl.tri_q.resize(big.size());
+      pl.sblk_tri_ptr.assign(pl.B + 1, 0);
+      for (size_t t = 0; t < big.size(); ++t) {
+        pl.tri_p[t] = big[t].second.first;
+        pl.tri_q[t] = big[t].second.second;
+        pl.sblk_tri_ptr[big[t].first + 1]++;
+      }
+      for (int64_t bk = 0; bk < pl.B; ++bk)
+        pl.sblk_tri_ptr[bk + 1] += pl.sblk_tri_ptr[bk];
+      make_chunks(pl.sblk_tri_ptr, (int)pl.B, kTriChunk, pl.tchunk_blk,
+                  pl.tchunk_begin, pl.tchunk_end, pl.sblk_tchunk_ptr);
+    }
+
+    // (b) Schur workgroups over the remaining landmarks
+    pl.swg_lm_begin.clear();
+    pl.swg_slot_ptr.assign(1, 0);
+    pl.slot_blk.clear();
+    pl.slot_tri_ptr.assign(1, 0);
+    pl.ltri.clear();
+    pl.ltri.reserve((size_t)(Tall - Tbig));
+    std::vector<std::pair<int32_t, uint32_t>> loc;  // (block, packed local pair ids)
+    std::vector<std::pair<int32_t, int32_t>> contrib;  // (block, flat slot)
+    int i = 0;
+    while (i < M) {
+      const int i0 = i;
+      const int64_t pbase = pl.lm_pair_ptr[i0];
+      int64_t np = 0;
+      while (i < M) {
+        const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
+        if (d > kSchurPairs) {  // big landmark: its own (empty) workgroup
+          if (i == i0) ++i;
+          break;
+        }
+        if (np + d > kSchurPairs || i - i0 >= kSchurLandmarks) break;
+        np += d;
+        ++i;
+      }
+      pl.swg_lm_begin.push_back(i0);
+      loc.clear();
+      for (int l = i0; l < i; ++l) {
+        const int64_t p0 = pl.lm_pair_ptr[l], p1 = pl.lm_pair_ptr[l + 1];
+        if (p1 - p0 > kSchurPairs) continue;
+        for (int64_t p = p0; p < p1; ++p)
+          for (int64_t q = p; q < p1; ++q)
+            loc.push_back({block_of(pl.pair_pose[p], pl.pair_pose[q]),
+                           (uint32_t)(((p - pbase) << 16) | (q - pbase))});
+      }
+      std::stable_sort(loc.begin(), loc.end(),
+                       [](const auto &x, const auto &y) { return x.first < y.first; });
+      for (size_t t = 0; t < loc.size(); ++t) {
+        if (t == 0 || loc[t].first != loc[t - 1].first) {
+          contrib.push_back({loc[t].first, (int32_t)pl.slot_blk.size()});
+          pl.slot_blk.push_back(loc[t].first);
+          if (pl.slot_blk.size() > 1) pl.slot_tri_ptr.push_back((int64_t)pl.ltri.size());
+        }
+        pl.ltri.push_back(loc[t].second);
+      }
+      pl.swg_slot_ptr.push_back((int32_t)pl.slot_blk.size());
+    }
+    pl.swg_lm_begin.push_back(M);
+    // slot_tri_ptr: one entry per slot start, close the CSR
+    if (pl.slot_blk.empty())
+      pl.slot_tri_ptr.assign(1, 0);
+    else
+      pl.slot_tri_ptr.push_back((int64_t)pl.ltri.size());
+    // per-block contribution lists (ascending workgroup = ascending slot id)
+    pl.blk_contrib_ptr.assign(pl.B + 1, 0);
+    for (auto &c2 : contrib) pl.blk_contrib_ptr[c2.first + 1]++;
+    for (int64_t bk = 0; bk < pl.B; ++bk)
+      pl.blk_contrib_ptr[bk + 1] += pl.blk_contrib_ptr[bk];
+    pl.contrib_slot.resize(contrib.size());
+    {
+      std::vector<int64_t> cur(pl.blk_contrib_ptr.begin(), pl.blk_contrib_ptr.end() - 1);
+      for (auto &c2 : contrib) pl.contrib_slot[cur[c2.first]++] = c2.second;
+    }
   }
 
   // ---- tile pattern of S (global: every shard factors the same matrix) ----

@@ -37,6 +37,8 @@ struct PlanInput {
 constexpr int kPoseChunk = 1024;   // observations per A/a partial-sum item
 constexpr int kRhsChunk = 1024;    // pairs per rhs partial-sum item
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
+constexpr int kSchurPairs = 192;      // pairs staged in LDS per Schur workgroup
+constexpr int kSchurLandmarks = 192;  // landmarks per Schur workgroup
 
 struct Plan {
   // ---- sizes ----
@@ -91,6 +93,15 @@ struct Plan {
   std::vector<int32_t> tchunk_blk;       // per Schur work item
   std::vector<int64_t> tchunk_begin, tchunk_end;
   std::vector<int32_t> sblk_tchunk_ptr;  // B+1
+  // (the global triple list above holds only landmarks with more than
+  //  kSchurPairs poses; everything else goes through the Schur workgroups)
+  std::vector<int32_t> swg_lm_begin;     // nswg+1 landmark ranges
+  std::vector<int32_t> swg_slot_ptr;     // nswg+1 -> slots
+  std::vector<int32_t> slot_blk;         // block of each slot
+  std::vector<int64_t> slot_tri_ptr;     // nslot+1 -> ltri
+  std::vector<uint32_t> ltri;            // (local pair p << 16) | local pair q
+  std::vector<int64_t> blk_contrib_ptr;  // B+1 -> contrib_slot
+  std::vector<int32_t> contrib_slot;     // slots of each block, workgroup order
   // ---- tile pattern of the GLOBAL reduced camera matrix (all shards) ----
   int ncb = 0;                           // tiles = groups of kPosesPerTile poses
   std::vector<uint8_t> tile_nz;          // ncb*ncb symmetric adjacency
