@@ -384,12 +384,23 @@ int ba_finalize(ba_handle *h) {
       h->upload(&d.tri_q, pl.tri_q) || h->upload(&d.tchunk_blk, pl.tchunk_blk) ||
       h->upload(&d.tchunk_begin, pl.tchunk_begin) || h->upload(&d.tchunk_end, pl.tchunk_end) ||
       h->upload(&d.sblk_tchunk_ptr, pl.sblk_tchunk_ptr) ||
-      h->upload(&d.swg_lm_begin, pl.swg_lm_begin) || h->upload(&d.swg_slot_ptr, pl.swg_slot_ptr) ||
-      h->upload(&d.slot_tri_ptr, pl.slot_tri_ptr) || h->upload(&d.ltri, pl.ltri) ||
+      h->upload(&d.ltri, pl.ltri) || h->upload(&d.chunk_sp, pl.chunk_sp) ||
       h->upload(&d.blk_contrib_ptr, pl.blk_contrib_ptr) || h->upload(&d.contrib_slot, pl.contrib_slot))
     return -1;
-  d.n_swg = (int)pl.swg_lm_begin.size() - 1;
+  d.n_sup = (int)pl.sup_desc.size();
   d.n_slot = (int)pl.slot_blk.size();
+  {
+    static_assert(sizeof(ba::Plan::SupDesc) == sizeof(ba::DevProblem::SupDesc), "desc layout");
+    static_assert(sizeof(ba::Plan::ChunkDesc) == sizeof(ba::DevProblem::ChunkDesc), "desc layout");
+    if (h->dalloc(&d.sup_desc, pl.sup_desc.size()) || h->dalloc(&d.chunk_desc, pl.chunk_desc.size()))
+      return -1;
+    if (!pl.sup_desc.empty())
+      HIP_TRY(hipMemcpy(d.sup_desc, pl.sup_desc.data(), pl.sup_desc.size() * sizeof(ba::Plan::SupDesc),
+                        hipMemcpyHostToDevice));
+    if (!pl.chunk_desc.empty())
+      HIP_TRY(hipMemcpy(d.chunk_desc, pl.chunk_desc.data(),
+                        pl.chunk_desc.size() * sizeof(ba::Plan::ChunkDesc), hipMemcpyHostToDevice));
+  }
   if (h->dalloc(&d.spart2, (size_t)d.n_slot * 36)) return -1;
 
   // per-iteration storage

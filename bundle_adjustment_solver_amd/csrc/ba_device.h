@@ -71,10 +71,18 @@ struct DevProblem {
   int32_t *tchunk_blk;
   int64_t *tchunk_begin, *tchunk_end;
   int32_t *sblk_tchunk_ptr;
-  // Schur workgroups (landmark-major, LDS slots)
-  int n_swg, n_slot;
-  int32_t *swg_lm_begin, *swg_slot_ptr;
-  int64_t *slot_tri_ptr;
+  // Schur super-runs (landmark-major, register-resident slot accumulators)
+  int n_sup, n_slot;
+  struct SupDesc {
+    int32_t s0, ns, chunk_begin, chunk_end;
+  };
+  struct ChunkDesc {
+    int64_t p0, tb, sp;
+    int32_t l0, nl, np, nt;
+  };
+  SupDesc *sup_desc;
+  ChunkDesc *chunk_desc;
+  uint16_t *chunk_sp;
   uint32_t *ltri;
   int64_t *blk_contrib_ptr;
   int32_t *contrib_slot;

@@ -407,49 +407,147 @@ __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
   d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = d.a[(size_t)j * 6 + r] - bc;
 }
 
-// Landmark-major Schur complement (reference :859-872): one workgroup per run
-// of consecutive landmarks.  W_ji and V_ji = W_ji Cinv_i of the run are staged
-// in LDS once (W is read from HBM exactly once), then the 36 entries of every
-// workgroup-local block slot are accumulated by 36 threads over the slot's
-// triple list in landmark order.  Slots of one block are summed across
-// workgroups by k_schur_final in workgroup order: deterministic, no atomics.
-__global__ __launch_bounds__(kBlock) void k_schur_lds(DevProblem d) {
-  if (d.ctrl->done) return;
-  __shared__ double Ws[kSchurPairs * 18];
-  __shared__ double Vs[kSchurPairs * 18];
-  const int wg = blockIdx.x;
-  const int s0 = d.swg_slot_ptr[wg], s1 = d.swg_slot_ptr[wg + 1];
-  if (s0 == s1) return;  // empty (big landmark handled by the triple list)
-  const int l0 = d.swg_lm_begin[wg], l1 = d.swg_lm_begin[wg + 1];
-  const int64_t p0 = d.lm_pair_ptr[l0];
-  const int np = (int)(d.lm_pair_ptr[l1] - p0);
-  // stage: one thread per (pair, row)
-  for (int t = threadIdx.x; t < np * 6; t += kBlock) {
-    const int lp = t / 6, r = t - lp * 6;
-    const double *Wp = d.W + (size_t)(p0 + lp) * 18 + r * 3;
-    const double w0 = Wp[0], w1 = Wp[1], w2 = Wp[2];
-    const double *ci = d.Cinv + (size_t)d.pair_lm[p0 + lp] * 6;
-    Ws[lp * 18 + r * 3 + 0] = w0;
-    Ws[lp * 18 + r * 3 + 1] = w1;
-    Ws[lp * 18 + r * 3 + 2] = w2;
-    Vs[lp * 18 + r * 3 + 0] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
-    Vs[lp * 18 + r * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
-    Vs[lp * 18 + r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+// Landmark-major Schur complement (reference :859-872).  One workgroup per
+// SUPER-RUN: a maximal run of consecutive landmarks (locality order) touching
+// at most kSchurSlots distinct blocks of S.  Every block (slot) of the run is
+// owned by `tps` lanes, each keeping a full 6x6 accumulator in registers for
+// the whole run.  The run's W blocks stream through LDS in CHUNKS
+// (<= kSchurPairs pairs): W is read from HBM exactly once, V = W Cinv is formed
+// in LDS and never stored.  The loads of chunk c+1 (all contiguous, all
+// independent) are issued into registers before chunk c is processed out of
+// LDS, so HBM latency is hidden.  One reduction over the tps lanes and one
+// 288-byte store per slot at the very end; slots of one block are summed
+// across super-runs by k_schur_final in run order: deterministic, no atomics.
+constexpr int kSchurRW = (kSchurPairs * 9 + kBlock - 1) / kBlock;
+constexpr int kSchurRC = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
+constexpr int kSchurRT = (kSchurTri + kBlock - 1) / kBlock;
+
+// issue the (contiguous, independent) global loads of one chunk into registers
+#define SCHUR_PREFETCH(cd_)                                                   \
+  {                                                                           \
+    const double2 *src_ = (const double2 *)(d.W + (size_t)(cd_).p0 * 18);     \
+    _Pragma("unroll") for (int k_ = 0; k_ < kSchurRW; ++k_) {                 \
+      const int t_ = tid + k_ * kBlock;                                       \
+      rw[k_] = (t_ < (cd_).np * 9) ? src_[t_] : make_double2(0.0, 0.0);       \
+    }                                                                         \
+    const double2 *cs_ = (const double2 *)(d.Cinv + (size_t)(cd_).l0 * 6);    \
+    _Pragma("unroll") for (int k_ = 0; k_ < kSchurRC; ++k_) {                 \
+      const int t_ = tid + k_ * kBlock;                                       \
+      rc[k_] = (t_ < (cd_).nl * 3) ? cs_[t_] : make_double2(0.0, 0.0);        \
+    }                                                                         \
+    _Pragma("unroll") for (int k_ = 0; k_ < kSchurRT; ++k_) {                 \
+      const int t_ = tid + k_ * kBlock;                                       \
+      rt[k_] = (t_ < (cd_).nt) ? d.ltri[(cd_).tb + t_] : 0u;                  \
+    }                                                                         \
+    rpl = (tid < (cd_).np) ? d.pair_lm[(cd_).p0 + tid] - (cd_).l0 : 0;        \
+    rsp = (tid <= ns) ? (int)d.chunk_sp[(cd_).sp + tid] : 0;                  \
   }
-  __syncthreads();
-  const int g = threadIdx.x / 36, e = threadIdx.x - g * 36;
-  if (g >= 7) return;
-  const int r = e / 6, c = e - r * 6;
-  for (int s = s0 + g; s < s1; s += 7) {
-    double acc = 0.0;
-    const int64_t t1 = d.slot_tri_ptr[s + 1];
-    for (int64_t t = d.slot_tri_ptr[s]; t < t1; ++t) {
-      const uint32_t pq = d.ltri[t];
-      const double *v = Vs + (pq >> 16) * 18 + r * 3;
-      const double *w = Ws + (pq & 0xffffu) * 18 + c * 3;
-      acc += v[0] * w[0] + v[1] * w[1] + v[2] * w[2];
+
+__global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
+  __shared__ __attribute__((aligned(16))) double Vs[kSchurPairs * 18];
+  __shared__ __attribute__((aligned(16))) double Cs[kSchurLandmarks * 6];
+  __shared__ uint32_t Ts[kSchurTri];
+  __shared__ uint16_t Sp[kSchurSlots + 1];
+  __shared__ uint16_t Pl[kSchurPairs];
+  const int tid = threadIdx.x;
+  const DevProblem::SupDesc sd = d.sup_desc[blockIdx.x];
+  const int ns = sd.ns;
+  // lanes per slot: largest power of two with ns * tps <= 256, at most 32
+  int tps = 32;
+  while (tps * ns > kBlock) tps >>= 1;
+  const int slot = tid / tps, sub = tid - slot * tps;
+  const bool owner = slot < ns;
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  DevProblem::ChunkDesc cd = d.chunk_desc[sd.chunk_begin];
+  double2 rw[kSchurRW], rc[kSchurRC];
+  uint32_t rt[kSchurRT];
+  int rpl, rsp;
+  SCHUR_PREFETCH(cd)
+  for (int ch = sd.chunk_begin; ch < sd.chunk_end; ++ch) {
+    // registers -> LDS
+    {
+      double2 *dst = (double2 *)Ws;
+#pragma unroll
+      for (int k = 0; k < kSchurRW; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < cd.np * 9) dst[t] = rw[k];
+      }
+      double2 *cdst = (double2 *)Cs;
+#pragma unroll
+      for (int k = 0; k < kSchurRC; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < cd.nl * 3) cdst[t] = rc[k];
+      }
+#pragma unroll
+      for (int k = 0; k < kSchurRT; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < cd.nt) Ts[t] = rt[k];
+      }
+      if (tid < cd.np) Pl[tid] = (uint16_t)rpl;
+      if (tid <= ns) Sp[tid] = (uint16_t)rsp;
     }
-    d.spart2[(size_t)s * 36 + e] = acc;
+    const int np = cd.np;
+    if (ch + 1 < sd.chunk_end) {  // next chunk's loads fly during this one
+      cd = d.chunk_desc[ch + 1];
+      SCHUR_PREFETCH(cd)
+    }
+    __syncthreads();
+    // V = W Cinv from LDS: one thread per (pair, row)
+    for (int t = tid; t < np * 6; t += kBlock) {
+      const int lp = t / 6;
+      const double *w = Ws + t * 3;
+      const double *ci = Cs + (int)Pl[lp] * 6;
+      const double w0 = w[0], w1 = w[1], w2 = w[2];
+      Vs[t * 3 + 0] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
+      Vs[t * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
+      Vs[t * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+    }
+    __syncthreads();
+    if (owner) {
+      const int t1 = (int)Sp[slot + 1];
+      for (int t = (int)Sp[slot] + sub; t < t1; t += tps) {
+        const uint32_t pq = Ts[t];
+        const double *vp = Vs + (pq >> 16) * 18;
+        const double2 *wp = (const double2 *)(Ws + (pq & 0xffffu) * 18);
+        double w[18];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double2 b2 = wp[k];
+          w[2 * k] = b2.x;
+          w[2 * k + 1] = b2.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double v0 = vp[r * 3 + 0], v1 = vp[r * 3 + 1], v2 = vp[r * 3 + 2];
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            acc[r * 6 + c] = fma(v2, w[c * 3 + 2],
+                                 fma(v1, w[c * 3 + 1],
+                                     fma(v0, w[c * 3 + 0], acc[r * 6 + c])));
+        }
+      }
+    }
+    __syncthreads();  // LDS is rewritten by the next chunk
+  }
+  // sum the tps lanes of every slot (fixed butterfly), store 288 B per slot
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    double a2 = acc[k];
+    if (tps > 16) a2 += __shfl_xor(a2, 16, 64);
+    if (tps > 8) a2 += __shfl_xor(a2, 8, 64);
+    if (tps > 4) a2 += __shfl_xor(a2, 4, 64);
+    if (tps > 2) a2 += __shfl_xor(a2, 2, 64);
+    if (tps > 1) a2 += __shfl_xor(a2, 1, 64);
+    acc[k] = a2;
+  }
+  if (owner && sub == 0) {
+    double *o = d.spart2 + (size_t)(sd.s0 + slot) * 36;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) o[k] = acc[k];
   }
 }
 
@@ -493,20 +591,31 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
 }
 
 // S_jk = delta_jk A_j - BCinvBt_jk, scattered into the dense column-major
-// lower matrix (reference :878-902). One thread per (block, entry).
+// lower matrix (reference :878-902).  One workgroup per block: 7 parts x 36
+// entries; part q sums every 7th slot partial of the block, the parts are then
+// added in order 0..6 (fixed tree: deterministic).
 __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
   if (d.ctrl->done) return;
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= d.B * 36) return;
-  const int64_t blk = t / 36;
-  const int e = (int)(t % 36);
+  __shared__ double part[7][36];
+  const int64_t blk = blockIdx.x;
+  const int q = threadIdx.x / 36, e = threadIdx.x - q * 36;
+  if (q < 7) {
+    double s = 0.0;
+    const int64_t c1 = d.blk_contrib_ptr[blk + 1];
+    for (int64_t cidx = d.blk_contrib_ptr[blk] + q; cidx < c1; cidx += 7)
+      s += d.spart2[(size_t)d.contrib_slot[cidx] * 36 + e];
+    const int ch1 = d.sblk_tchunk_ptr[blk + 1];
+    for (int ch = d.sblk_tchunk_ptr[blk] + q; ch < ch1; ch += 7)
+      s += d.spart[(size_t)ch * 36 + e];
+    part[q][e] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 36) return;
+  double s = part[0][e];
+#pragma unroll
+  for (int k = 1; k < 7; ++k) s += part[k][e];
   const int r = e / 6, c = e % 6;
   const int j = d.sblk_j[blk], k = d.sblk_k[blk];
-  double s = 0.0;
-  for (int64_t q = d.blk_contrib_ptr[blk]; q < d.blk_contrib_ptr[blk + 1]; ++q)
-    s += d.spart2[(size_t)d.contrib_slot[q] * 36 + e];
-  for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
-    s += d.spart[(size_t)ch * 36 + e];
   const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
   // S_jk[r][c] lives at dense (row, col) = (col_of(k)+c, col_of(j)+r) or its
   // transpose, whichever is in the LOWER triangle under the tile ordering
@@ -778,13 +887,13 @@ void launch_schur(const DevProblem &d, hipStream_t s) {
   if (d.N > 0)
     hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)),
                        dim3(kBlock), 0, s, d);
-  if (d.n_swg > 0)
-    hipLaunchKernelGGL(k_schur_lds, dim3(d.n_swg), dim3(kBlock), 0, s, d);
+  if (d.n_sup > 0)
+    hipLaunchKernelGGL(k_schur_lds, dim3(d.n_sup), dim3(kBlock), 0, s, d);
   if (d.n_tchunk > 0)
     hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
   if (d.B > 0)
-    hipLaunchKernelGGL(k_schur_final, dim3(cdiv(d.B * 36, kBlock)),
-                       dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s,
+                       d);
 }
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s) {

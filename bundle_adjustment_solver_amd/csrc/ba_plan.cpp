@@ -295,12 +295,16 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       return (int32_t)(std::lower_bound(b0, e0, k) - &pl.sblk_k[0]);
     };
 
+    auto is_big = [&](int64_t d) {
+      return d * (d + 1) / 2 > kSchurTri || d * (d + 1) / 2 > kSchurSlots ||
+             d > kSchurPairs;
+    };
     // (a) big landmarks -> global triple list sorted by (block, landmark)
     int64_t Tbig = 0, Tall = 0;
     for (int i = 0; i < M; ++i) {
       const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
       Tall += d * (d + 1) / 2;
-      if (d > kSchurPairs) Tbig += d * (d + 1) / 2;
+      if (is_big(d)) Tbig += d * (d + 1) / 2;
     }
     pl.T = Tall;
     {
@@ -308,7 +312,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       big.reserve(Tbig);
       for (int i = 0; i < M; ++i) {
         const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
-        if (p1 - p0 <= kSchurPairs) continue;
+        if (!is_big(p1 - p0)) continue;
         for (int64_t p = p0; p < p1; ++p)
           for (int64_t q = p; q < p1; ++q)
             big.push_back({block_of(pl.pair_pose[p], pl.pair_pose[q]), {p, q}});
@@ -329,59 +333,121 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
                   pl.tchunk_begin, pl.tchunk_end, pl.sblk_tchunk_ptr);
     }
 
-    // (b) Schur workgroups over the remaining landmarks
-    pl.swg_lm_begin.clear();
-    pl.swg_slot_ptr.assign(1, 0);
+    // (b) SUPER-RUNS over the remaining landmarks: maximal runs of consecutive
+    // landmarks (locality order) that touch at most kSchurSlots distinct
+    // blocks; one workgroup per super-run keeps one 6x6 accumulator per
+    // (slot, lane) in registers while it streams the run's W blocks through
+    // LDS in CHUNKS (<= kSchurPairs pairs, <= kSchurTri triples).
+    pl.sup_desc.clear();
+    pl.chunk_desc.clear();
     pl.slot_blk.clear();
-    pl.slot_tri_ptr.assign(1, 0);
     pl.ltri.clear();
     pl.ltri.reserve((size_t)(Tall - Tbig));
-    std::vector<std::pair<int32_t, uint32_t>> loc;  // (block, packed local pair ids)
+    pl.chunk_sp.clear();
     std::vector<std::pair<int32_t, int32_t>> contrib;  // (block, flat slot)
+    std::vector<int32_t> mark(pl.B, -1);               // block -> local slot
+    std::vector<int32_t> sup_blocks;
+    std::vector<std::pair<int32_t, uint32_t>> loc;
     int i = 0;
     while (i < M) {
+      // ---- grow a super-run ----
       const int i0 = i;
-      const int64_t pbase = pl.lm_pair_ptr[i0];
-      int64_t np = 0;
-      while (i < M) {
-        const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
-        if (d > kSchurPairs) {  // big landmark: its own (empty) workgroup
-          if (i == i0) ++i;
+      sup_blocks.clear();
+      while (i < M && i - i0 < kSchurSuperLandmarks) {
+        const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
+        if (is_big(p1 - p0)) {
+          if (i == i0) ++i;  // big landmark alone (handled by the triple list)
           break;
         }
-        if (np + d > kSchurPairs || i - i0 >= kSchurLandmarks) break;
-        np += d;
+        // blocks this landmark would add
+        const size_t before = sup_blocks.size();
+        for (int64_t p = p0; p < p1; ++p)
+          for (int64_t q = p; q < p1; ++q) {
+            const int32_t bk = block_of(pl.pair_pose[p], pl.pair_pose[q]);
+            if (mark[bk] < 0) {
+              mark[bk] = (int32_t)sup_blocks.size();
+              sup_blocks.push_back(bk);
+            }
+          }
+        if ((int)sup_blocks.size() > kSchurSlots && i > i0) {
+          for (size_t s = before; s < sup_blocks.size(); ++s) mark[sup_blocks[s]] = -1;
+          sup_blocks.resize(before);
+          break;
+        }
         ++i;
       }
-      pl.swg_lm_begin.push_back(i0);
-      loc.clear();
-      for (int l = i0; l < i; ++l) {
-        const int64_t p0 = pl.lm_pair_ptr[l], p1 = pl.lm_pair_ptr[l + 1];
-        if (p1 - p0 > kSchurPairs) continue;
-        for (int64_t p = p0; p < p1; ++p)
-          for (int64_t q = p; q < p1; ++q)
-            loc.push_back({block_of(pl.pair_pose[p], pl.pair_pose[q]),
-                           (uint32_t)(((p - pbase) << 16) | (q - pbase))});
+      const int i1 = i;
+      const int ns = (int)sup_blocks.size();
+      bool any = false;
+      for (int l = i0; l < i1; ++l)
+        any = any || !is_big(pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l]);
+      if (!any || ns == 0) {
+        for (int32_t bk : sup_blocks) mark[bk] = -1;
+        continue;
       }
-      std::stable_sort(loc.begin(), loc.end(),
-                       [](const auto &x, const auto &y) { return x.first < y.first; });
-      for (size_t t = 0; t < loc.size(); ++t) {
-        if (t == 0 || loc[t].first != loc[t - 1].first) {
-          contrib.push_back({loc[t].first, (int32_t)pl.slot_blk.size()});
-          pl.slot_blk.push_back(loc[t].first);
-          if (pl.slot_blk.size() > 1) pl.slot_tri_ptr.push_back((int64_t)pl.ltri.size());
+      if (ns > kSchurSlots) {  // one landmark with too many blocks: cannot be
+        // register-resident -> leave it to the global triple list
+        for (int32_t bk : sup_blocks) mark[bk] = -1;
+        return "internal: landmark exceeds kSchurSlots blocks but not kSchurTri";
+      }
+      // slots sorted by block id for a stable order
+      std::vector<int32_t> order(sup_blocks);
+      std::sort(order.begin(), order.end());
+      for (int s = 0; s < ns; ++s) mark[order[s]] = s;
+      Plan::SupDesc sd;
+      sd.s0 = (int32_t)pl.slot_blk.size();
+      sd.ns = ns;
+      sd.chunk_begin = (int32_t)pl.chunk_desc.size();
+      for (int s = 0; s < ns; ++s) {
+        contrib.push_back({order[s], sd.s0 + s});
+        pl.slot_blk.push_back(order[s]);
+      }
+      // ---- chunks ----
+      int l = i0;
+      while (l < i1) {
+        const int c0 = l;
+        const int64_t pbase = pl.lm_pair_ptr[c0];
+        int64_t np = 0, nt = 0;
+        while (l < i1) {
+          const int64_t d = pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l];
+          const int64_t dt = d * (d + 1) / 2;
+          if (l > c0 && (np + d > kSchurPairs || nt + dt > kSchurTri ||
+                         l - c0 >= kSchurLandmarks))
+            break;
+          np += d;
+          nt += dt;
+          ++l;
         }
-        pl.ltri.push_back(loc[t].second);
+        loc.clear();
+        for (int m = c0; m < l; ++m)
+          for (int64_t p = pl.lm_pair_ptr[m]; p < pl.lm_pair_ptr[m + 1]; ++p)
+            for (int64_t q = p; q < pl.lm_pair_ptr[m + 1]; ++q)
+              loc.push_back({mark[block_of(pl.pair_pose[p], pl.pair_pose[q])],
+                             (uint32_t)(((p - pbase) << 16) | (q - pbase))});
+        std::stable_sort(loc.begin(), loc.end(),
+                         [](const auto &x, const auto &y) { return x.first < y.first; });
+        Plan::ChunkDesc cd;
+        cd.p0 = pbase;
+        cd.tb = (int64_t)pl.ltri.size();
+        cd.sp = (int64_t)pl.chunk_sp.size();
+        cd.l0 = c0;
+        cd.nl = l - c0;
+        cd.np = (int32_t)np;
+        cd.nt = (int32_t)loc.size();
+        // per-slot offsets into this chunk's triple list
+        size_t t = 0;
+        for (int s = 0; s <= ns; ++s) {
+          while (t < loc.size() && loc[t].first < s) ++t;
+          pl.chunk_sp.push_back((uint16_t)t);
+        }
+        for (auto &e : loc) pl.ltri.push_back(e.second);
+        pl.chunk_desc.push_back(cd);
       }
-      pl.swg_slot_ptr.push_back((int32_t)pl.slot_blk.size());
+      sd.chunk_end = (int32_t)pl.chunk_desc.size();
+      pl.sup_desc.push_back(sd);
+      for (int32_t bk : sup_blocks) mark[bk] = -1;
     }
-    pl.swg_lm_begin.push_back(M);
-    // slot_tri_ptr: one entry per slot start, close the CSR
-    if (pl.slot_blk.empty())
-      pl.slot_tri_ptr.assign(1, 0);
-    else
-      pl.slot_tri_ptr.push_back((int64_t)pl.ltri.size());
-    // per-block contribution lists (ascending workgroup = ascending slot id)
+    // per-block contribution lists (ascending super-run = ascending slot id)
     pl.blk_contrib_ptr.assign(pl.B + 1, 0);
     for (auto &c2 : contrib) pl.blk_contrib_ptr[c2.first + 1]++;
     for (int64_t bk = 0; bk < pl.B; ++bk)

@@ -37,8 +37,11 @@ struct PlanInput {
 constexpr int kPoseChunk = 1024;   // observations per A/a partial-sum item
 constexpr int kRhsChunk = 1024;    // pairs per rhs partial-sum item
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
-constexpr int kSchurPairs = 192;      // pairs staged in LDS per Schur workgroup
-constexpr int kSchurLandmarks = 192;  // landmarks per Schur workgroup
+constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
+constexpr int kSchurLandmarks = 128;  // landmarks per chunk
+constexpr int kSchurTri = 1024;       // triples per chunk (LDS resident)
+constexpr int kSchurSlots = 128;      // distinct blocks per super-run (>= 2 lanes each)
+constexpr int kSchurSuperLandmarks = 256;  // landmarks per super-run
 
 struct Plan {
   // ---- sizes ----
@@ -93,12 +96,20 @@ struct Plan {
   std::vector<int32_t> tchunk_blk;       // per Schur work item
   std::vector<int64_t> tchunk_begin, tchunk_end;
   std::vector<int32_t> sblk_tchunk_ptr;  // B+1
-  // (the global triple list above holds only landmarks with more than
-  //  kSchurPairs poses; everything else goes through the Schur workgroups)
-  std::vector<int32_t> swg_lm_begin;     // nswg+1 landmark ranges
-  std::vector<int32_t> swg_slot_ptr;     // nswg+1 -> slots
+  // (the global triple list above holds only "big" landmarks; everything
+  //  else goes through the super-runs below)
+  struct SupDesc {                       // one Schur workgroup
+    int32_t s0, ns;                      // its slots [s0, s0+ns)
+    int32_t chunk_begin, chunk_end;      // its chunks
+  };
+  struct ChunkDesc {                     // <= kSchurPairs pairs staged at once
+    int64_t p0, tb, sp;                  // first pair, first triple, chunk_sp base
+    int32_t l0, nl, np, nt;              // landmarks, pairs, triples
+  };
+  std::vector<SupDesc> sup_desc;
+  std::vector<ChunkDesc> chunk_desc;
+  std::vector<uint16_t> chunk_sp;        // per chunk: ns+1 slot offsets
   std::vector<int32_t> slot_blk;         // block of each slot
-  std::vector<int64_t> slot_tri_ptr;     // nslot+1 -> ltri
   std::vector<uint32_t> ltri;            // (local pair p << 16) | local pair q
   std::vector<int64_t> blk_contrib_ptr;  // B+1 -> contrib_slot
   std::vector<int32_t> contrib_slot;     // slots of each block, workgroup order
