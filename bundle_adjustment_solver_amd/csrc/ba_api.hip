@@ -379,7 +379,7 @@ int ba_finalize(ba_handle *h) {
       h->upload(&d.achunk_end, pl.achunk_end) || h->upload(&d.pose_achunk_ptr, pl.pose_achunk_ptr) ||
       h->upload(&d.ppair, pl.ppair) || h->upload(&d.rchunk_pose, pl.rchunk_pose) ||
       h->upload(&d.rchunk_begin, pl.rchunk_begin) || h->upload(&d.rchunk_end, pl.rchunk_end) ||
-      h->upload(&d.pose_rchunk_ptr, pl.pose_rchunk_ptr) || h->upload(&d.sblk_j, pl.sblk_j) ||
+      h->upload(&d.pose_rchunk_ptr, pl.pose_rchunk_ptr) || h->upload(&d.sblk_j, pl.sblk_j) || h->upload(&d.diag_blk, pl.diag_blk) ||
       h->upload(&d.sblk_k, pl.sblk_k) || h->upload(&d.tri_p, pl.tri_p) ||
       h->upload(&d.tri_q, pl.tri_q) || h->upload(&d.tchunk_blk, pl.tchunk_blk) ||
       h->upload(&d.tchunk_begin, pl.tchunk_begin) || h->upload(&d.tchunk_end, pl.tchunk_end) ||
@@ -388,6 +388,8 @@ int ba_finalize(ba_handle *h) {
       h->upload(&d.blk_contrib_ptr, pl.blk_contrib_ptr) || h->upload(&d.contrib_slot, pl.contrib_slot))
     return -1;
   d.n_sup = (int)pl.sup_desc.size();
+  d.n_bchunk = (int)pl.bchunk_lm.size() - 1;
+  if (h->upload(&d.bchunk_lm, pl.bchunk_lm)) return -1;
   d.n_slot = (int)pl.slot_blk.size();
   {
     static_assert(sizeof(ba::Plan::SupDesc) == sizeof(ba::DevProblem::SupDesc), "desc layout");
@@ -401,7 +403,7 @@ int ba_finalize(ba_handle *h) {
       HIP_TRY(hipMemcpy(d.chunk_desc, pl.chunk_desc.data(),
                         pl.chunk_desc.size() * sizeof(ba::Plan::ChunkDesc), hipMemcpyHostToDevice));
   }
-  if (h->dalloc(&d.spart2, (size_t)d.n_slot * 36)) return -1;
+  if (h->dalloc(&d.spart2, (size_t)d.n_slot * ba::kSlotStride)) return -1;
 
   // per-iteration storage
   if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.b, (size_t)pl.M * 3) ||
@@ -409,17 +411,17 @@ int ba_finalize(ba_handle *h) {
       h->dalloc(&d.W, (size_t)pl.P * 18) ||
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) || h->dalloc(&d.A, (size_t)pl.N * 36) ||
       h->dalloc(&d.a, (size_t)pl.N * 6) || h->dalloc(&d.rpart, (size_t)d.n_rchunk * 6) ||
-      h->dalloc(&d.spart, (size_t)d.n_tchunk * 36) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
+      h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
       h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
-      h->dalloc(&d.lm_part, (size_t)ba::kLmGrid * 2) || h->dalloc(&d.pose_part, (size_t)2) ||
+      h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_bchunk) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
       h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
     return -1;
   HIP_TRY(hipMemset(d.W, 0, std::max<size_t>(1, (size_t)pl.P * 18) * sizeof(double)));
   HIP_TRY(hipMemset(d.x, 0, ((size_t)pl.N * 6 + 64) * sizeof(double)));
   HIP_TRY(hipMemset(d.y, 0, std::max<size_t>(1, (size_t)pl.M * 3) * sizeof(double)));
   HIP_TRY(hipMemset(d.cost_part, 0, ba::kCostGrid * sizeof(double)));
-  HIP_TRY(hipMemset(d.lm_part, 0, ba::kLmGrid * 2 * sizeof(double)));
-  HIP_TRY(hipMemset(d.pose_part, 0, 2 * sizeof(double)));
+  HIP_TRY(hipMemset(d.lm_part, 0, (size_t)std::max(1, d.n_bchunk) * 2 * sizeof(double)));
+  HIP_TRY(hipMemset(d.pose_part, 0, (2 + 2 * ba::kPoseGrid) * sizeof(double)));
   HIP_TRY(hipMemset(d.scal, 0, 4 * sizeof(double)));
   d.log_cap = 4096;
   if (h->dalloc(&d.log, (size_t)d.log_cap)) return -1;
@@ -458,6 +460,19 @@ int ba_finalize(ba_handle *h) {
       return -1;
     dd.col_x = d.col_x;
     HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
+    // tiles (re)initialised per iteration: factor pattern + diagonal + rhs row
+    std::vector<int> ztI, ztJ;
+    for (int p = 0; p < ncb; ++p) {
+      ztI.push_back(p);
+      ztJ.push_back(p);
+      for (int q = sc.row_ptr[p]; q < sc.row_ptr[p + 1]; ++q) {
+        ztI.push_back(sc.rows[q]);  // includes the rhs row block (== ncb)
+        ztJ.push_back(p);
+      }
+    }
+    d.n_zt = (int)ztI.size();
+    if (h->upload(&d.zt_I, ztI) || h->upload(&d.zt_J, ztJ)) return -1;
+    HIP_TRY(hipMemset(d.L, 0, (size_t)h->xbuf_n[0] * sizeof(double)));
   }
 
   std::memset(&h->hc, 0, sizeof(h->hc));
@@ -486,8 +501,11 @@ int ba_bind_reduce_buffer(ba_handle *h, int which, void *dev_ptr, int64_t n) {
   if (!h || !h->finalized) return fail("ba_bind_reduce_buffer: not finalized");
   if (which < 0 || which > 1 || !dev_ptr || n < h->xbuf_n[which])
     return fail("ba_bind_reduce_buffer: bad argument");
-  if (which == 0)
+  if (which == 0) {
     h->d.L = (double *)dev_ptr;
+    // tiles outside the factor pattern are never written: they must be zero
+    HIP_TRY(hipMemset(dev_ptr, 0, (size_t)h->xbuf_n[0] * sizeof(double)));
+  }
   else
     h->d.scal = (double *)dev_ptr;
   return 0;

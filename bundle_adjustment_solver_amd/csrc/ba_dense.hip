@@ -24,15 +24,20 @@ namespace {
 constexpr int NB = kDenseNb;  // 64
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_dense_init(double *L, int npad, int ld,
+// (Re)initialise the tiles of L that the factorisation touches: the
+// structurally non-zero tiles of the factor (incl. fill-in), the diagonal tiles
+// (unit diagonal on padding columns) and the rhs row block.  Every other tile
+// was zeroed once at ba_finalize and is never written.
+__global__ __launch_bounds__(256) void k_dense_init(double *L, int ld,
                                                     const int *__restrict__ col_x,
+                                                    const int *__restrict__ zt_I,
+                                                    const int *__restrict__ zt_J,
                                                     const int *done) {
   if (done && *done) return;
-  for (int c = blockIdx.x; c < npad; c += gridDim.x) {
-    double *col = L + (size_t)c * ld;
-    const bool pad = col_x[c] < 0;  // padding column: unit diagonal
-    for (int r = threadIdx.x; r < ld; r += blockDim.x)
-      col[r] = (pad && r == c) ? 1.0 : 0.0;
+  const int I = zt_I[blockIdx.x], J = zt_J[blockIdx.x];
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int c = J * NB + e / NB, r = I * NB + e % NB;
+    L[(size_t)c * ld + r] = (r == c && col_x[c] < 0) ? 1.0 : 0.0;
   }
 }
 
@@ -360,10 +365,12 @@ __global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
 
 }  // namespace
 
-void launch_dense_init(double *L, int npad, int ld, const int *col_x,
-                       const int *done_flag, hipStream_t s) {
-  hipLaunchKernelGGL(k_dense_init, dim3(2048), dim3(256), 0, s, L, npad, ld,
-                     col_x, done_flag);
+void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
+                       const int *zt_J, int n_zt, const int *done_flag,
+                       hipStream_t s) {
+  if (n_zt > 0)
+    hipLaunchKernelGGL(k_dense_init, dim3(n_zt), dim3(256), 0, s, L, ld, col_x,
+                       zt_I, zt_J, done_flag);
 }
 
 // Level-scheduled, structure-aware blocked Cholesky (see ba_dense_sched.h):

@@ -67,6 +67,7 @@ struct DevProblem {
   int32_t *pose_rchunk_ptr;
   // Schur structure
   int32_t *sblk_j, *sblk_k;
+  int32_t *diag_blk;
   int64_t *tri_p, *tri_q;
   int32_t *tchunk_blk;
   int64_t *tchunk_begin, *tchunk_end;
@@ -86,7 +87,7 @@ struct DevProblem {
   uint32_t *ltri;
   int64_t *blk_contrib_ptr;
   int32_t *contrib_slot;
-  double *spart2;  // n_slot*36 slot partial sums
+  double *spart2;  // n_slot*kSlotStride slot partial sums (36 of S + 6 of rhs)
   // per-iteration blocks
   double *Cd;      // M*6   damped C_i upper (00 01 02 11 12 22)
   double *b;       // M*3
@@ -97,13 +98,14 @@ struct DevProblem {
   double *A;       // N*36  damped, full
   double *a;       // N*6
   double *rpart;   // n_rchunk*6
-  double *spart;   // n_tchunk*36
+  double *spart;   // n_tchunk*kSlotStride
   double *x;       // 6N
   double *y;       // M*3
   // scalar reductions
   double *cost_part;   // kCostGrid
   double *lm_part;     // kLmGrid*2 : model (landmark side), sum |y|
-  double *pose_part;   // 2 : model (pose side), sum |x|
+  double *pose_part;   // [0..1] totals, then kPoseGrid*2 block partials:
+                       // model (pose side), sum |x|
   double *scal;        // exchange buffer 1: [0] cost [1] model est [2] sum|y|
   // controller
   DevCtrl *ctrl;
@@ -115,10 +117,16 @@ struct DevProblem {
   double *Ldiag;   // (npad/64) * kDenseWsPerBlock (diagonal factors + inverses)
   int *pose_col;   // N: first dense column of optimised pose j
   int *col_x;      // npad: dense column -> 6*pose + r, or -1 (padding)
+  int32_t *bchunk_lm;  // n_bchunk+1 landmark ranges (backsub)
+  int n_bchunk;
+  int *zt_I, *zt_J;  // tiles of L that are (re)initialised every iteration
+  int n_zt;
 };
 
 constexpr int kCostGrid = 1024;
 constexpr int kLmGrid = 1024;
+constexpr int kPoseGrid = 16;
+constexpr int kSlotStride = 42;  // 6x6 block of B Cinv B^T + 6 of B Cinv b
 constexpr int kDenseNb = 64;
 // dense workspace per 64-column block: L11 (64x64) + four 16x16 tile inverses
 constexpr int kDenseWsPerBlock = 64 * 64 + 4 * 256;
@@ -153,8 +161,9 @@ void launch_dense_solve(const DevProblem &d, const DenseSchedule &sc,
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const int *done_flag, const DenseSchedule &sc,
                         const DenseDev &dd, hipStream_t s);
-void launch_dense_init(double *L, int npad, int ld, const int *col_x,
-                       const int *done_flag, hipStream_t s);
+void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
+                       const int *zt_J, int n_zt, const int *done_flag,
+                       hipStream_t s);
 
 // ---- pose-only (ba_pose_only.hip) ----
 struct PoIter {

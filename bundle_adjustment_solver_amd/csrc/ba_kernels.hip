@@ -225,55 +225,101 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
 }
 
 // --------------------------------------------------------------------------
-// landmark side of the linearisation, one thread per optimisable landmark
+// landmark side of the linearisation (reference :716-831, :846-856).
+// One workgroup per chunk of consecutive landmarks (the chunks of the
+// back-substitution: <= kSchurLandmarks landmarks, <= kSchurPairs pairs).
+// Phase A, one thread per OBSERVATION (coalesced 16-byte record loads):
+//   residual, weight, G, R = G R_jw; its C_i / b_i contribution (9 doubles) goes
+//   to LDS, its cross block W_ji = w Q^T R (if it is the pair's last writer,
+//   reference :826) to an LDS image of the chunk's W range.
+// Phase B, one thread per LANDMARK: sums its observations' contributions in
+//   insertion order (deterministic), damps, inverts (pivoted 3x3 LDL^T with
+//   pseudo-inverse) and stores Cd, b, Cinv, Cinv b.
+// The W image is written back with contiguous 16-byte stores.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
   if (d.ctrl->done) return;
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= d.M) return;
+  __shared__ __attribute__((aligned(16))) double Wst[kSchurPairs * 18];
+  __shared__ double Cb[kBlock * 9];
+  const int tid = threadIdx.x;
   const int buf = d.ctrl->cur;
   const double huber = d.ctrl->huber;
   const double lp1 = 1.0 + d.ctrl->lambda;
   const double *__restrict__ poses = d.poses[buf];
-  const double *X = d.pts[buf] + (size_t)i * 3;
-  const double X0 = X[0], X1 = X[1], X2 = X[2];
+  const double *__restrict__ pts = d.pts[buf];
+  const int l0 = d.bchunk_lm[blockIdx.x], l1 = d.bchunk_lm[blockIdx.x + 1];
+  const int64_t pb = d.lm_pair_ptr[l0];
+  const int npair = (int)(d.lm_pair_ptr[l1] - pb);
+  const int64_t ob = d.lm_obs_ptr[l0], oe = d.lm_obs_ptr[l1];
+  const int i = l0 + tid;
+  const bool own = i < l1;
+  int64_t q0 = 0, q1 = 0;
+  if (own) {
+    q0 = d.lm_obs_ptr[i];
+    q1 = d.lm_obs_ptr[i + 1];
+  }
   double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
   double b0 = 0, b1 = 0, b2 = 0;
-  const int64_t s0 = d.lm_obs_ptr[i], s1 = d.lm_obs_ptr[i + 1];
-  for (int64_t s = s0; s < s1; ++s) {
-    const int4 id = d.obs_idx[s];
-    const double2 uv = d.obs_uv[s];
-    const double *cam = d.cams + id.x * 16;
-    const double *T = poses + (size_t)id.y * 12;
-    ObsGeom g;
-    project(cam, T, X0, X1, X2, uv.x, uv.y, g);
-    double w, G[6], Rm[6];
-    weight_and_G(cam, g, huber, w, G);
-    make_R(G, T, Rm);
-    // reference :503-517, :817-823
-    c00 += w * (Rm[0] * Rm[0] + Rm[3] * Rm[3]);
-    c01 += w * (Rm[0] * Rm[1] + Rm[3] * Rm[4]);
-    c02 += w * (Rm[0] * Rm[2] + Rm[3] * Rm[5]);
-    c11 += w * (Rm[1] * Rm[1] + Rm[4] * Rm[4]);
-    c12 += w * (Rm[1] * Rm[2] + Rm[4] * Rm[5]);
-    c22 += w * (Rm[2] * Rm[2] + Rm[5] * Rm[5]);
-    const double wr0 = w * g.r0, wr1 = w * g.r1;
-    b0 -= Rm[0] * wr0 + Rm[3] * wr1;
-    b1 -= Rm[1] * wr0 + Rm[4] * wr1;
-    b2 -= Rm[2] * wr0 + Rm[5] * wr1;
-    if (id.w >= 0) {
-      // B_ji = w Q^T R, kept only from the last-inserted observation of the
-      // pair (reference :826)
-      double Q[12];
-      make_Q(G, g.Xij, Q);
-      double *Wp = d.W + (size_t)id.w * 18;
+  for (int64_t t0 = ob; t0 < oe; t0 += kBlock) {
+    const int64_t s = t0 + tid;
+    if (s < oe) {
+      const int4 id = d.obs_idx[s];
+      const double2 uv = d.obs_uv[s];
+      const double *cam = d.cams + id.x * 16;
+      const double *T = poses + (size_t)id.y * 12;
+      const double *X = pts + (size_t)id.z * 3;
+      ObsGeom g;
+      project(cam, T, X[0], X[1], X[2], uv.x, uv.y, g);
+      double w, G[6], Rm[6];
+      weight_and_G(cam, g, huber, w, G);
+      make_R(G, T, Rm);
+      // reference :503-517, :817-823
+      double *cb = Cb + tid * 9;
+      cb[0] = w * (Rm[0] * Rm[0] + Rm[3] * Rm[3]);
+      cb[1] = w * (Rm[0] * Rm[1] + Rm[3] * Rm[4]);
+      cb[2] = w * (Rm[0] * Rm[2] + Rm[3] * Rm[5]);
+      cb[3] = w * (Rm[1] * Rm[1] + Rm[4] * Rm[4]);
+      cb[4] = w * (Rm[1] * Rm[2] + Rm[4] * Rm[5]);
+      cb[5] = w * (Rm[2] * Rm[2] + Rm[5] * Rm[5]);
+      const double wr0 = w * g.r0, wr1 = w * g.r1;
+      cb[6] = Rm[0] * wr0 + Rm[3] * wr1;
+      cb[7] = Rm[1] * wr0 + Rm[4] * wr1;
+      cb[8] = Rm[2] * wr0 + Rm[5] * wr1;
+      if (id.w >= 0) {
+        // B_ji = w Q^T R, kept only from the last-inserted observation of the
+        // pair (reference :826)
+        double Q[12];
+        make_Q(G, g.Xij, Q);
+        const int lp = (int)(id.w - pb);
+        double *Wp = (lp < kSchurPairs) ? (Wst + lp * 18)
+                                        : (d.W + (size_t)id.w * 18);
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          Wp[r * 3 + c] = w * (Q[r] * Rm[c] + Q[6 + r] * Rm[3 + c]);
+          for (int c = 0; c < 3; ++c)
+            Wp[r * 3 + c] = w * (Q[r] * Rm[c] + Q[6 + r] * Rm[3 + c]);
+      }
     }
+    __syncthreads();
+    if (own) {
+      const int64_t a = max(q0, t0), b = min(q1, t0 + kBlock);
+      for (int64_t q = a; q < b; ++q) {
+        const double *cb = Cb + (q - t0) * 9;
+        c00 += cb[0]; c01 += cb[1]; c02 += cb[2];
+        c11 += cb[3]; c12 += cb[4]; c22 += cb[5];
+        b0 -= cb[6]; b1 -= cb[7]; b2 -= cb[8];
+      }
+    }
+    __syncthreads();
   }
+  // W image -> global (contiguous)
+  {
+    const int n2 = min(npair, kSchurPairs) * 9;
+    const double2 *src = (const double2 *)Wst;
+    double2 *dst = (double2 *)(d.W + (size_t)pb * 18);
+    for (int t = tid; t < n2; t += kBlock) dst[t] = src[t];
+  }
+  if (!own) return;
   // reference :846-856
   double cd[6] = {c00 * lp1, c01, c02, c11 * lp1, c12, c22 * lp1};
   double ci[6];
@@ -288,10 +334,10 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
   double *Io = d.Cinv + (size_t)i * 6;
 #pragma unroll
   for (int k = 0; k < 6; ++k) Io[k] = ci[k];
-  double *cb = d.Cinvb + (size_t)i * 3;
-  cb[0] = ci[0] * b0 + ci[1] * b1 + ci[2] * b2;
-  cb[1] = ci[1] * b0 + ci[3] * b1 + ci[4] * b2;
-  cb[2] = ci[2] * b0 + ci[4] * b1 + ci[5] * b2;
+  double *cbo = d.Cinvb + (size_t)i * 3;
+  cbo[0] = ci[0] * b0 + ci[1] * b1 + ci[2] * b2;
+  cbo[1] = ci[1] * b0 + ci[3] * b1 + ci[4] * b2;
+  cbo[2] = ci[2] * b0 + ci[4] * b1 + ci[5] * b2;
 }
 
 // --------------------------------------------------------------------------
@@ -342,31 +388,6 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   }
 }
 
-// partial sums of BCinv_b_j = sum_i B_ji (Cinv_i b_i) over a chunk of pose j's
-// pairs (reference :864; B Cinv is never materialised: (B Cinv) b = B (Cinv b))
-__global__ __launch_bounds__(kBlock) void k_rhs_partial(DevProblem d) {
-  if (d.ctrl->done) return;
-  __shared__ double sm[4];
-  const int ch = blockIdx.x;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  const int64_t e = d.rchunk_end[ch];
-  for (int64_t s = d.rchunk_begin[ch] + threadIdx.x; s < e; s += kBlock) {
-    const int64_t p = d.ppair[s];
-    const int i = d.pair_lm[p];
-    const double *Wp = d.W + (size_t)p * 18;
-    const double *cb = d.Cinvb + (size_t)i * 3;
-    const double b0 = cb[0], b1 = cb[1], b2 = cb[2];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-      acc[r] += Wp[r * 3 + 0] * b0 + Wp[r * 3 + 1] * b1 + Wp[r * 3 + 2] * b2;
-  }
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const double tot = block_sum(acc[r], sm);
-    if (threadIdx.x == 0) d.rpart[(size_t)ch * 6 + r] = tot;
-  }
-}
-
 // A_j (mirrored, damped) and a_j from the partial sums.
 // One thread per (pose, component): 21 upper + 6 gradient entries.
 __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
@@ -395,15 +416,20 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
 }
 
 // rhs_j = a_j - BCinv_b_j (reference :887-888); rides as row `npad` of the
-// dense system.  One thread per (pose, component).
+// dense system.  BCinv_b_j = sum_i V_ji b_i is accumulated next to the diagonal
+// block (j,j) by the Schur kernels (entries 36..41 of every slot partial).
+// One thread per (pose, component); runs after the Schur kernels.
 __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
   if (d.ctrl->done) return;
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= d.N * 6) return;
   const int j = t / 6, r = t % 6;
+  const int64_t blk = d.diag_blk[j];
   double bc = 0.0;
-  for (int ch = d.pose_rchunk_ptr[j]; ch < d.pose_rchunk_ptr[j + 1]; ++ch)
-    bc += d.rpart[(size_t)ch * 6 + r];
+  for (int64_t q = d.blk_contrib_ptr[blk]; q < d.blk_contrib_ptr[blk + 1]; ++q)
+    bc += d.spart2[(size_t)d.contrib_slot[q] * kSlotStride + 36 + r];
+  for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
+    bc += d.spart[(size_t)ch * kSlotStride + 36 + r];
   d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = d.a[(size_t)j * 6 + r] - bc;
 }
 
@@ -421,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
 constexpr int kSchurRW = (kSchurPairs * 9 + kBlock - 1) / kBlock;
 constexpr int kSchurRC = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
 constexpr int kSchurRT = (kSchurTri + kBlock - 1) / kBlock;
+constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
 
 // issue the (contiguous, independent) global loads of one chunk into registers
 #define SCHUR_PREFETCH(cd_)                                                   \
@@ -439,15 +466,20 @@ constexpr int kSchurRT = (kSchurTri + kBlock - 1) / kBlock;
       const int t_ = tid + k_ * kBlock;                                       \
       rt[k_] = (t_ < (cd_).nt) ? d.ltri[(cd_).tb + t_] : 0u;                  \
     }                                                                         \
+    _Pragma("unroll") for (int k_ = 0; k_ < kSchurRB; ++k_) {                 \
+      const int t_ = tid + k_ * kBlock;                                       \
+      rb[k_] = (t_ < (cd_).nl * 3) ? d.b[(size_t)(cd_).l0 * 3 + t_] : 0.0;    \
+    }                                                                         \
     rpl = (tid < (cd_).np) ? d.pair_lm[(cd_).p0 + tid] - (cd_).l0 : 0;        \
     rsp = (tid <= ns) ? (int)d.chunk_sp[(cd_).sp + tid] : 0;                  \
   }
 
-__global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
+__global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   if (d.ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Vs[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Cs[kSchurLandmarks * 6];
+  __shared__ double Bs[kSchurLandmarks * 3];
   __shared__ uint32_t Ts[kSchurTri];
   __shared__ uint16_t Sp[kSchurSlots + 1];
   __shared__ uint16_t Pl[kSchurPairs];
@@ -459,12 +491,15 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   while (tps * ns > kBlock) tps >>= 1;
   const int slot = tid / tps, sub = tid - slot * tps;
   const bool owner = slot < ns;
-  double acc[36];
+  double acc[36], racc[6];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) racc[k] = 0.0;
   DevProblem::ChunkDesc cd = d.chunk_desc[sd.chunk_begin];
   double2 rw[kSchurRW], rc[kSchurRC];
   uint32_t rt[kSchurRT];
+  double rb[kSchurRB];
   int rpl, rsp;
   SCHUR_PREFETCH(cd)
   for (int ch = sd.chunk_begin; ch < sd.chunk_end; ++ch) {
@@ -486,6 +521,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
       for (int k = 0; k < kSchurRT; ++k) {
         const int t = tid + k * kBlock;
         if (t < cd.nt) Ts[t] = rt[k];
+      }
+#pragma unroll
+      for (int k = 0; k < kSchurRB; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < cd.nl * 3) Bs[t] = rb[k];
       }
       if (tid < cd.np) Pl[tid] = (uint16_t)rpl;
       if (tid <= ns) Sp[tid] = (uint16_t)rsp;
@@ -513,6 +553,11 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
         const uint32_t pq = Ts[t];
         const double *vp = Vs + (pq >> 16) * 18;
         const double2 *wp = (const double2 *)(Ws + (pq & 0xffffu) * 18);
+        // diagonal triple (p == q): also B Cinv b of this pair (reference :864)
+        const bool dg = (pq >> 16) == (pq & 0xffffu);
+        const double *bp = Bs + (int)Pl[pq >> 16] * 3;
+        const double b0 = dg ? bp[0] : 0.0, b1 = dg ? bp[1] : 0.0,
+                     b2 = dg ? bp[2] : 0.0;
         double w[18];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -528,6 +573,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
             acc[r * 6 + c] = fma(v2, w[c * 3 + 2],
                                  fma(v1, w[c * 3 + 1],
                                      fma(v0, w[c * 3 + 0], acc[r * 6 + c])));
+          racc[r] = fma(v2, b2, fma(v1, b1, fma(v0, b0, racc[r])));
         }
       }
     }
@@ -544,10 +590,22 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
     if (tps > 1) a2 += __shfl_xor(a2, 1, 64);
     acc[k] = a2;
   }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double a2 = racc[k];
+    if (tps > 16) a2 += __shfl_xor(a2, 16, 64);
+    if (tps > 8) a2 += __shfl_xor(a2, 8, 64);
+    if (tps > 4) a2 += __shfl_xor(a2, 4, 64);
+    if (tps > 2) a2 += __shfl_xor(a2, 2, 64);
+    if (tps > 1) a2 += __shfl_xor(a2, 1, 64);
+    racc[k] = a2;
+  }
   if (owner && sub == 0) {
-    double *o = d.spart2 + (size_t)(sd.s0 + slot) * 36;
+    double *o = d.spart2 + (size_t)(sd.s0 + slot) * kSlotStride;
 #pragma unroll
     for (int k = 0; k < 36; ++k) o[k] = acc[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[36 + k] = racc[k];
   }
 }
 
@@ -556,15 +614,20 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
 __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
   if (d.ctrl->done) return;
   const int ch = blockIdx.x;
-  double acc[36];
+  double acc[36], racc[6];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) racc[k] = 0.0;
   const int64_t e = d.tchunk_end[ch];
   for (int64_t t = d.tchunk_begin[ch] + threadIdx.x; t < e; t += 64) {
     const int64_t p = d.tri_p[t];
+    const bool dg = p == d.tri_q[t];
     const double *Wp = d.W + (size_t)p * 18;
     const double *Wq = d.W + (size_t)d.tri_q[t] * 18;
     const double *ci = d.Cinv + (size_t)d.pair_lm[p] * 6;
+    const double *bi = d.b + (size_t)d.pair_lm[p] * 3;
+    const double b0 = dg ? bi[0] : 0.0, b1 = dg ? bi[1] : 0.0, b2 = dg ? bi[2] : 0.0;
     double v[18], w[18];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -572,6 +635,7 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
       v[r * 3 + 0] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
       v[r * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
       v[r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+      racc[r] += v[r * 3 + 0] * b0 + v[r * 3 + 1] * b1 + v[r * 3 + 2] * b2;
     }
 #pragma unroll
     for (int k = 0; k < 18; ++k) w[k] = Wq[k];
@@ -586,7 +650,12 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
 #pragma unroll
   for (int k = 0; k < 36; ++k) {
     const double tot = wave_sum(acc[k]);
-    if (threadIdx.x == 0) d.spart[(size_t)ch * 36 + k] = tot;
+    if (threadIdx.x == 0) d.spart[(size_t)ch * kSlotStride + k] = tot;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double tot = wave_sum(racc[k]);
+    if (threadIdx.x == 0) d.spart[(size_t)ch * kSlotStride + 36 + k] = tot;
   }
 }
 
@@ -603,10 +672,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
     double s = 0.0;
     const int64_t c1 = d.blk_contrib_ptr[blk + 1];
     for (int64_t cidx = d.blk_contrib_ptr[blk] + q; cidx < c1; cidx += 7)
-      s += d.spart2[(size_t)d.contrib_slot[cidx] * 36 + e];
+      s += d.spart2[(size_t)d.contrib_slot[cidx] * kSlotStride + e];
     const int ch1 = d.sblk_tchunk_ptr[blk + 1];
     for (int ch = d.sblk_tchunk_ptr[blk] + q; ch < ch1; ch += 7)
-      s += d.spart[(size_t)ch * 36 + e];
+      s += d.spart[(size_t)ch * kSlotStride + e];
     part[q][e] = s;
   }
   __syncthreads();
@@ -635,29 +704,60 @@ __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
 // y_i = Cinv_i b_i - Cinv_i (sum_j B_ji^T x_j)  (reference :910-917; CinvBt is
 // never materialised) — the same vector sum_j B_ji^T x_j is the cross term of
 // the quadratic model (reference :447-452), so W is read once.
+// One workgroup per chunk of consecutive landmarks (<= kSchurPairs pairs per
+// tile): the W blocks are copied to LDS with contiguous 16-byte loads, lane
+// (pair, c) forms u_c = sum_r W[r][c] x_j[r], then one thread per landmark sums
+// its pairs and finishes y, the trial point and the model terms.
 __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
   if (d.ctrl->done) return;
+  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
+  __shared__ double Us[kSchurPairs * 3];
   __shared__ double sm[4];
+  const int tid = threadIdx.x;
   const int cur = d.ctrl->cur;
   const double *__restrict__ Xc = d.pts[cur];
   double *__restrict__ Xt = d.pts[cur ^ 1];
-  double est = 0.0, nrm = 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.M;
-       i += gridDim.x * kBlock) {
-    double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
-    for (int64_t p = d.lm_pair_ptr[i]; p < d.lm_pair_ptr[i + 1]; ++p) {
-      const double *xj = d.x + (size_t)d.pair_pose[p] * 6;
-      const double *Wp = d.W + (size_t)p * 18;
-      double u0 = 0, u1 = 0, u2 = 0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const double xr = xj[r];
-        u0 += Wp[r * 3 + 0] * xr;
-        u1 += Wp[r * 3 + 1] * xr;
-        u2 += Wp[r * 3 + 2] * xr;
-      }
-      bx0 += u0; bx1 += u1; bx2 += u2;
+  const int l0 = d.bchunk_lm[blockIdx.x], l1 = d.bchunk_lm[blockIdx.x + 1];
+  const int64_t pb = d.lm_pair_ptr[l0], pe = d.lm_pair_ptr[l1];
+  const int i = l0 + tid;  // landmark owned by this thread (if any)
+  const bool own = i < l1;
+  int64_t q0 = 0, q1 = 0;
+  if (own) {
+    q0 = d.lm_pair_ptr[i];
+    q1 = d.lm_pair_ptr[i + 1];
+  }
+  double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
+  for (int64_t t0 = pb; t0 < pe; t0 += kSchurPairs) {
+    const int np = (int)min((int64_t)kSchurPairs, pe - t0);
+    {
+      const double2 *src = (const double2 *)(d.W + (size_t)t0 * 18);
+      double2 *dst = (double2 *)Ws;
+      for (int t = tid; t < np * 9; t += kBlock) dst[t] = src[t];
     }
+    __syncthreads();
+    for (int t = tid; t < np * 3; t += kBlock) {
+      const int lp = t / 3, c = t - lp * 3;
+      const double *xj = d.x + (size_t)d.pair_pose[t0 + lp] * 6;
+      const double *w = Ws + lp * 18 + c;
+      double u = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) u = fma(w[r * 3], xj[r], u);
+      Us[t] = u;
+    }
+    __syncthreads();
+    if (own) {
+      const int64_t a = max(q0, t0), b = min(q1, t0 + np);
+      for (int64_t p = a; p < b; ++p) {
+        const double *u = Us + (p - t0) * 3;
+        bx0 += u[0];
+        bx1 += u[1];
+        bx2 += u[2];
+      }
+    }
+    __syncthreads();
+  }
+  double est = 0.0, nrm = 0.0;
+  if (own) {
     const double *ci = d.Cinv + (size_t)i * 6;
     const double *cb = d.Cinvb + (size_t)i * 3;
     const double y0 = cb[0] - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);
@@ -674,24 +774,25 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
     const double *bi = d.b + (size_t)i * 3;
     const double *C = d.Cd + (size_t)i * 6;
     double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;
-    const double q0 = y0 * C[0] + y1 * C[1] + y2 * C[2];
-    const double q1 = y0 * C[1] + y1 * C[3] + y2 * C[4];
-    const double q2 = y0 * C[2] + y1 * C[4] + y2 * C[5];
-    e += q0 * y0 + q1 * y1 + q2 * y2;
+    const double r0 = y0 * C[0] + y1 * C[1] + y2 * C[2];
+    const double r1 = y0 * C[1] + y1 * C[3] + y2 * C[4];
+    const double r2 = y0 * C[2] + y1 * C[4] + y2 * C[5];
+    e += r0 * y0 + r1 * y1 + r2 * y2;
     e += 2.0 * (y0 * bx0 + y1 * bx1 + y2 * bx2);
-    est += e;
-    nrm += sqrt(y0 * y0 + y1 * y1 + y2 * y2);
+    est = e;
+    nrm = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
   }
-  const double t0 = block_sum(est, sm);
-  const double t1 = block_sum(nrm, sm);
-  if (threadIdx.x == 0) {
-    d.lm_part[2 * blockIdx.x + 0] = t0;
-    d.lm_part[2 * blockIdx.x + 1] = t1;
+  const double s0 = block_sum(est, sm);
+  const double s1 = block_sum(nrm, sm);
+  if (tid == 0) {
+    d.lm_part[2 * blockIdx.x + 0] = s0;
+    d.lm_part[2 * blockIdx.x + 1] = s1;
   }
 }
 
 // se3 exponential (reference :1046-1082) composed onto T_jw (:487-494),
-// pose-side model terms (:437-441) and sum |x_j| (:962).  Single block.
+// pose-side model terms (:437-441) and sum |x_j| (:962).  Block b writes its
+// partial sums to pose_part[2 + 2b ..]; k_scalars adds them in block order.
 __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
   if (d.ctrl->done) return;
   __shared__ double sm[4];
@@ -699,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
   const double *__restrict__ Tc = d.poses[cur];
   double *__restrict__ Tt = d.poses[cur ^ 1];
   double est = 0.0, nrm = 0.0;
-  for (int j = threadIdx.x; j < d.N; j += kBlock) {
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.N; j += gridDim.x * kBlock) {
     const double *xj = d.x + (size_t)j * 6;
     const double v0 = xj[0], v1 = xj[1], v2 = xj[2];
     const double w0 = xj[3], w1 = xj[4], w2 = xj[5];
@@ -767,8 +868,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
   const double t0 = block_sum(est, sm);
   const double t1 = block_sum(nrm, sm);
   if (threadIdx.x == 0) {
-    d.pose_part[0] = t0;
-    d.pose_part[1] = t1;
+    d.pose_part[2 + 2 * blockIdx.x + 0] = t0;
+    d.pose_part[2 + 2 * blockIdx.x + 1] = t1;
   }
 }
 
@@ -778,19 +879,34 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
 __global__ __launch_bounds__(kBlock) void k_scalars(DevProblem d, int mode) {
   if (d.ctrl->done) return;
   __shared__ double sm[4];
-  double c = 0.0, e = 0.0, n = 0.0;
+  double c = 0.0, e = 0.0, n = 0.0, pe = 0.0, pn = 0.0;
+#pragma unroll 4
   for (int k = threadIdx.x; k < kCostGrid; k += kBlock) c += d.cost_part[k];
-  if (mode == 1)
-    for (int k = threadIdx.x; k < kLmGrid; k += kBlock) {
-      e += d.lm_part[2 * k + 0];
-      n += d.lm_part[2 * k + 1];
+  if (mode == 1) {
+    const double2 *lp = (const double2 *)d.lm_part;
+#pragma unroll 8
+    for (int k = threadIdx.x; k < d.n_bchunk; k += kBlock) {
+      const double2 v = lp[k];
+      e += v.x;
+      n += v.y;
     }
+    if (threadIdx.x < kPoseGrid) {
+      pe = d.pose_part[2 + 2 * threadIdx.x + 0];
+      pn = d.pose_part[2 + 2 * threadIdx.x + 1];
+    }
+  }
   const double tc = block_sum(c, sm);
   const double te = block_sum(e, sm);
   const double tn = block_sum(n, sm);
+  const double tpe = block_sum(pe, sm);
+  const double tpn = block_sum(pn, sm);
   if (threadIdx.x == 0) {
+    if (mode == 1) {
+      d.pose_part[0] = tpe;
+      d.pose_part[1] = tpn;
+    }
     d.scal[0] = tc;
-    d.scal[1] = (mode == 1) ? te + d.pose_part[0] : 0.0;
+    d.scal[1] = (mode == 1) ? te + tpe : 0.0;
     d.scal[2] = (mode == 1) ? tn : 0.0;
     d.scal[3] = 0.0;
   }
@@ -870,9 +986,8 @@ void launch_cost(const DevProblem &d, int sel, hipStream_t s) {
 }
 
 void launch_linearize(const DevProblem &d, hipStream_t s) {
-  if (d.M > 0)
-    hipLaunchKernelGGL(k_lin_landmarks, dim3(cdiv(d.M, kBlock)), dim3(kBlock),
-                       0, s, d);
+  if (d.n_bchunk > 0)
+    hipLaunchKernelGGL(k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
   if (d.n_achunk > 0)
     hipLaunchKernelGGL(k_lin_poses, dim3(d.n_achunk), dim3(kBlock), 0, s, d);
   if (d.N > 0)
@@ -881,24 +996,23 @@ void launch_linearize(const DevProblem &d, hipStream_t s) {
 }
 
 void launch_schur(const DevProblem &d, hipStream_t s) {
-  launch_dense_init(d.L, d.npad, d.ld, d.col_x, &d.ctrl->done, s);
-  if (d.n_rchunk > 0)
-    hipLaunchKernelGGL(k_rhs_partial, dim3(d.n_rchunk), dim3(kBlock), 0, s, d);
-  if (d.N > 0)
-    hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)),
-                       dim3(kBlock), 0, s, d);
+  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, &d.ctrl->done, s);
   if (d.n_sup > 0)
     hipLaunchKernelGGL(k_schur_lds, dim3(d.n_sup), dim3(kBlock), 0, s, d);
   if (d.n_tchunk > 0)
     hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
+  if (d.N > 0)
+    hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)),
+                       dim3(kBlock), 0, s, d);
   if (d.B > 0)
     hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s,
                        d);
 }
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_backsub_update, dim3(kLmGrid), dim3(kBlock), 0, s, d);
-  hipLaunchKernelGGL(k_pose_update, dim3(1), dim3(kBlock), 0, s, d);
+  if (d.n_bchunk > 0)
+    hipLaunchKernelGGL(k_backsub_update, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+  hipLaunchKernelGGL(k_pose_update, dim3(kPoseGrid), dim3(kBlock), 0, s, d);
 }
 
 void launch_scalars(const DevProblem &d, hipStream_t s) {

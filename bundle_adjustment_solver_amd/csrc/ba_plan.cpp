@@ -289,6 +289,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       blk_row_ptr[j + 1] = (int64_t)pl.sblk_j.size();
     }
     pl.B = (int64_t)pl.sblk_j.size();
+    pl.diag_blk.resize(N);
+    for (int j = 0; j < N; ++j) pl.diag_blk[j] = (int32_t)blk_row_ptr[j];  // (j,j) leads row j
     auto block_of = [&](int32_t j, int32_t k) -> int32_t {
       const int32_t *b0 = &pl.sblk_k[blk_row_ptr[j]];
       const int32_t *e0 = &pl.sblk_k[blk_row_ptr[j + 1]];
@@ -456,6 +458,24 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     {
       std::vector<int64_t> cur(pl.blk_contrib_ptr.begin(), pl.blk_contrib_ptr.end() - 1);
       for (auto &c2 : contrib) pl.contrib_slot[cur[c2.first]++] = c2.second;
+    }
+  }
+
+  // ---- back-substitution chunks: consecutive landmarks, <= kSchurPairs pairs
+  // (a landmark with more pairs forms a chunk of its own) ----
+  {
+    pl.bchunk_lm.assign(1, 0);
+    int l = 0;
+    while (l < M) {
+      int64_t np = 0;
+      const int c0 = l;
+      while (l < M && l - c0 < kSchurLandmarks) {
+        const int64_t dd = pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l];
+        if (l > c0 && np + dd > kSchurPairs) break;
+        np += dd;
+        ++l;
+      }
+      pl.bchunk_lm.push_back(l);
     }
   }
 

@@ -34,7 +34,7 @@ struct PlanInput {
 };
 
 // Work-item granularities (shared with the kernels).
-constexpr int kPoseChunk = 1024;   // observations per A/a partial-sum item
+constexpr int kPoseChunk = 4096;   // observations per A/a partial-sum item
 constexpr int kRhsChunk = 1024;    // pairs per rhs partial-sum item
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
 constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
@@ -91,6 +91,7 @@ struct Plan {
   std::vector<int32_t> pose_rchunk_ptr;  // N+1
   // ---- Schur triples ----
   std::vector<int32_t> sblk_j, sblk_k;   // B
+  std::vector<int32_t> diag_blk;         // N: block id of (j,j)
   std::vector<int64_t> sblk_tri_ptr;     // B+1
   std::vector<int64_t> tri_p, tri_q;     // T : pair ids (pose j side, k side)
   std::vector<int32_t> tchunk_blk;       // per Schur work item
@@ -113,6 +114,7 @@ struct Plan {
   std::vector<uint32_t> ltri;            // (local pair p << 16) | local pair q
   std::vector<int64_t> blk_contrib_ptr;  // B+1 -> contrib_slot
   std::vector<int32_t> contrib_slot;     // slots of each block, workgroup order
+  std::vector<int32_t> bchunk_lm;        // landmark ranges of the backsub chunks
   // ---- tile pattern of the GLOBAL reduced camera matrix (all shards) ----
   int ncb = 0;                           // tiles = groups of kPosesPerTile poses
   std::vector<uint8_t> tile_nz;          // ncb*ncb symmetric adjacency
