@@ -114,7 +114,7 @@ inline void mark(ba_handle *h, int k) {
 
 int xchg(ba_handle *h, int which) {
   if (!h->ar_fn) return 0;
-  void *ptr = which == 0 ? (void *)h->d.L : (void *)h->d.scal;
+  void *ptr = which == 0 ? (void *)h->d.Spk : (void *)h->d.scal;
   int rc = h->ar_fn(h->ar_user, which, ptr, h->xbuf_n[which], (void *)h->stream);
   if (rc != 0) return fail("all-reduce hook returned an error");
   return 0;
@@ -131,6 +131,7 @@ int enqueue_iteration(ba_handle *h) {
   mark(h, 2);
   if (xchg(h, 0)) return -1;
   mark(h, 3);
+  ba::launch_scatter(d, s);
   ba::launch_dense_solve(d, h->sched, h->ddev, s);
   mark(h, 4);
   ba::launch_backsub_update(d, s);
@@ -437,9 +438,10 @@ int ba_finalize(ba_handle *h) {
     ba::build_dense_schedule(ncb, adj, nat && atoi(nat) != 0, h->sched);
     d.npad = ncb * ba::kDenseNb;
     d.ld = d.npad + ba::kDenseNb;
-    h->xbuf_n[0] = (int64_t)d.npad * d.ld;
+    h->xbuf_n[0] = pl.B * 36 + 6 * (int64_t)pl.N;
     h->xbuf_n[1] = 4;
-    if (h->dalloc(&d.L, (size_t)h->xbuf_n[0])) return -1;
+    if (h->dalloc(&d.Spk, (size_t)h->xbuf_n[0])) return -1;
+    if (h->dalloc(&d.L, (size_t)d.npad * d.ld)) return -1;
     if (h->dalloc(&d.Ldiag, (size_t)ncb * ba::kDenseWsPerBlock)) return -1;
     h->pose_col_h.assign(pl.N, 0);
     std::vector<int> col_x((size_t)d.npad, -1);
@@ -472,7 +474,8 @@ int ba_finalize(ba_handle *h) {
     }
     d.n_zt = (int)ztI.size();
     if (h->upload(&d.zt_I, ztI) || h->upload(&d.zt_J, ztJ)) return -1;
-    HIP_TRY(hipMemset(d.L, 0, (size_t)h->xbuf_n[0] * sizeof(double)));
+    HIP_TRY(hipMemset(d.L, 0, (size_t)d.npad * d.ld * sizeof(double)));
+    HIP_TRY(hipMemset(d.Spk, 0, (size_t)h->xbuf_n[0] * sizeof(double)));
   }
 
   std::memset(&h->hc, 0, sizeof(h->hc));
@@ -501,11 +504,8 @@ int ba_bind_reduce_buffer(ba_handle *h, int which, void *dev_ptr, int64_t n) {
   if (!h || !h->finalized) return fail("ba_bind_reduce_buffer: not finalized");
   if (which < 0 || which > 1 || !dev_ptr || n < h->xbuf_n[which])
     return fail("ba_bind_reduce_buffer: bad argument");
-  if (which == 0) {
-    h->d.L = (double *)dev_ptr;
-    // tiles outside the factor pattern are never written: they must be zero
-    HIP_TRY(hipMemset(dev_ptr, 0, (size_t)h->xbuf_n[0] * sizeof(double)));
-  }
+  if (which == 0)
+    h->d.Spk = (double *)dev_ptr;
   else
     h->d.scal = (double *)dev_ptr;
   return 0;
@@ -639,6 +639,7 @@ int ba_stage_schur(ba_handle *h) {
 int ba_stage_solve_reduced(ba_handle *h) {
   if (!h || !h->finalized) return fail("ba_stage_solve_reduced: not finalized");
   if (use_device(h)) return -1;
+  ba::launch_scatter(h->d, h->stream);  // packed (reduced) S||rhs -> dense
   ba::launch_dense_solve(h->d, h->sched, h->ddev, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
@@ -797,6 +798,7 @@ int ba_get_S(ba_handle *h, double *S, double *rhs) {
   const ba::DevProblem &d = h->d;
   const int n6 = 6 * h->plan.N;
   std::vector<double> L;
+  ba::launch_scatter(d, h->stream);  // from the packed exchange buffer
   if (download(L, d.L, (size_t)d.npad * d.ld, h->stream)) return -1;
   auto colof = [&](int e) { return h->pose_col_h[e / 6] + e % 6; };
   for (int c = 0; c < n6; ++c) {

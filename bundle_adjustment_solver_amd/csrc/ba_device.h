@@ -111,7 +111,9 @@ struct DevProblem {
   DevCtrl *ctrl;
   DevIterRec *log;
   int log_cap;
-  // dense reduced system (exchange buffer 0): column-major lower, ld rows
+  // packed reduced system (exchange buffer 0): B*36 block entries, then 6N rhs
+  double *Spk;
+  // dense reduced system: column-major lower, ld rows (rhs rides as row npad)
   double *L;
   int npad, ld;
   double *Ldiag;   // (npad/64) * kDenseWsPerBlock (diagonal factors + inverses)
@@ -137,6 +139,7 @@ void launch_cost(const DevProblem &d, int sel, hipStream_t s);
 void launch_linearize(const DevProblem &d, hipStream_t s);
 void launch_schur(const DevProblem &d, hipStream_t s);
 void launch_backsub_update(const DevProblem &d, hipStream_t s);
+void launch_scatter(const DevProblem &d, hipStream_t s);
 void launch_scalars(const DevProblem &d, hipStream_t s);
 void launch_control(const DevProblem &d, hipStream_t s);
 void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s);

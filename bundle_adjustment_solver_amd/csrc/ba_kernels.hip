@@ -415,8 +415,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
   }
 }
 
-// rhs_j = a_j - BCinv_b_j (reference :887-888); rides as row `npad` of the
-// dense system.  BCinv_b_j = sum_i V_ji b_i is accumulated next to the diagonal
+// rhs_j = a_j - BCinv_b_j (reference :887-888), written to the packed exchange
+// buffer behind the S blocks.  BCinv_b_j = sum_i V_ji b_i is accumulated next to the diagonal
 // block (j,j) by the Schur kernels (entries 36..41 of every slot partial).
 // One thread per (pose, component); runs after the Schur kernels.
 __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
     bc += d.spart2[(size_t)d.contrib_slot[q] * kSlotStride + 36 + r];
   for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
     bc += d.spart[(size_t)ch * kSlotStride + 36 + r];
-  d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = d.a[(size_t)j * 6 + r] - bc;
+  d.Spk[(size_t)d.B * 36 + t] = d.a[(size_t)j * 6 + r] - bc;
 }
 
 // Landmark-major Schur complement (reference :859-872).  One workgroup per
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
   }
 }
 
-// S_jk = delta_jk A_j - BCinvBt_jk, scattered into the dense column-major
-// lower matrix (reference :878-902).  One workgroup per block: 7 parts x 36
+// S_jk = delta_jk A_j - BCinvBt_jk into the packed exchange buffer (reference
+// :878-888).  One workgroup per block: 7 parts x 36
 // entries; part q sums every 7th slot partial of the block, the parts are then
 // added in order 0..6 (fixed tree: deterministic).
 __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
@@ -683,9 +683,27 @@ __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
   double s = part[0][e];
 #pragma unroll
   for (int k = 1; k < 7; ++k) s += part[k][e];
+  const int j = d.sblk_j[blk], k = d.sblk_k[blk];
+  d.Spk[(size_t)blk * 36 + e] = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
+}
+
+// Packed S blocks and rhs -> dense column-major lower matrix (reference
+// :892-902), after the multi-GPU all-reduce of the packed buffer.
+__global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
+  if (d.ctrl->done) return;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t nb = d.B * 36;
+  if (t >= nb + 6 * (int64_t)d.N) return;
+  const double val = d.Spk[t];
+  if (t >= nb) {  // rhs rides as row `npad`
+    const int e = (int)(t - nb);
+    d.L[(size_t)(d.pose_col[e / 6] + e % 6) * d.ld + d.npad] = val;
+    return;
+  }
+  const int64_t blk = t / 36;
+  const int e = (int)(t - blk * 36);
   const int r = e / 6, c = e % 6;
   const int j = d.sblk_j[blk], k = d.sblk_k[blk];
-  const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
   // S_jk[r][c] lives at dense (row, col) = (col_of(k)+c, col_of(j)+r) or its
   // transpose, whichever is in the LOWER triangle under the tile ordering
   int row = d.pose_col[k] + c, col = d.pose_col[j] + r;
@@ -1007,6 +1025,12 @@ void launch_schur(const DevProblem &d, hipStream_t s) {
   if (d.B > 0)
     hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s,
                        d);
+}
+
+void launch_scatter(const DevProblem &d, hipStream_t s) {
+  const int64_t n = d.B * 36 + 6 * (int64_t)d.N;
+  if (n > 0)
+    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, s, d);
 }
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s) {

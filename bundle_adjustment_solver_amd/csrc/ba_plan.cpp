@@ -264,17 +264,44 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   // slots of each block in workgroup order (deterministic).  Landmarks seen by
   // more than kSchurPairs poses go through the global (j,k)-sorted triple list.
   {
-    // block set as a CSR over pose rows
+    // block set as a CSR over pose rows.  It is the GLOBAL set (all shards use
+    // the same block numbering: the packed S||rhs exchange buffer is indexed
+    // by block), so with world > 1 it is built from the full observation list.
     std::vector<std::vector<int32_t>> rowk(N);
     for (int j = 0; j < N; ++j) rowk[j].push_back(j);
-    for (int i = 0; i < M; ++i)
-      for (int64_t p = pl.lm_pair_ptr[i]; p < pl.lm_pair_ptr[i + 1]; ++p) {
-        auto &rk = rowk[pl.pair_pose[p]];
-        for (int64_t q = p; q < pl.lm_pair_ptr[i + 1]; ++q) {
-          const int32_t k = pl.pair_pose[q];
-          if (rk.empty() || rk.back() != k) rk.push_back(k);
+    if (in.world == 1) {
+      for (int i = 0; i < M; ++i)
+        for (int64_t p = pl.lm_pair_ptr[i]; p < pl.lm_pair_ptr[i + 1]; ++p) {
+          auto &rk = rowk[pl.pair_pose[p]];
+          for (int64_t q = p; q < pl.lm_pair_ptr[i + 1]; ++q) {
+            const int32_t k = pl.pair_pose[q];
+            if (rk.empty() || rk.back() != k) rk.push_back(k);
+          }
         }
+    } else {
+      std::vector<uint64_t> keys;
+      keys.reserve(in.n_obs);
+      for (int64_t k = 0; k < in.n_obs; ++k) {
+        const int j = pl.pose_int_of_user[in.obs_pose[k]];
+        if (j < N && !in.pt_fixed[in.obs_pt[k]])
+          keys.push_back(((uint64_t)(uint32_t)in.obs_pt[k] << 32) | (uint32_t)j);
       }
+      std::sort(keys.begin(), keys.end());
+      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+      size_t a = 0;
+      while (a < keys.size()) {
+        size_t b = a;
+        while (b < keys.size() && (keys[b] >> 32) == (keys[a] >> 32)) ++b;
+        for (size_t u = a; u < b; ++u) {
+          auto &rk = rowk[(int)(uint32_t)keys[u]];
+          for (size_t v = u; v < b; ++v) {
+            const int32_t k = (int32_t)(uint32_t)keys[v];
+            if (rk.empty() || rk.back() != k) rk.push_back(k);
+          }
+        }
+        a = b;
+      }
+    }
     std::vector<int64_t> blk_row_ptr(N + 1, 0);
     pl.sblk_j.clear();
     pl.sblk_k.clear();
@@ -491,29 +518,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       pl.tile_nz[(size_t)a * ncb + b] = 1;
       pl.tile_nz[(size_t)b * ncb + a] = 1;
     };
-    if (in.world == 1) {
-      for (int64_t bk = 0; bk < pl.B; ++bk) mark(pl.sblk_j[bk], pl.sblk_k[bk]);
-    } else {
-      // all (landmark, pose) pairs of the FULL problem, both optimisable
-      std::vector<uint64_t> keys;
-      keys.reserve(in.n_obs);
-      for (int64_t k = 0; k < in.n_obs; ++k) {
-        const int j = pl.pose_int_of_user[in.obs_pose[k]];
-        if (j < N && !in.pt_fixed[in.obs_pt[k]])
-          keys.push_back(((uint64_t)(uint32_t)in.obs_pt[k] << 32) | (uint32_t)j);
-      }
-      std::sort(keys.begin(), keys.end());
-      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-      size_t a = 0;
-      while (a < keys.size()) {
-        size_t b = a;
-        while (b < keys.size() && (keys[b] >> 32) == (keys[a] >> 32)) ++b;
-        for (size_t u = a; u < b; ++u)
-          for (size_t v = u; v < b; ++v)
-            mark((int)(uint32_t)keys[u], (int)(uint32_t)keys[v]);
-        a = b;
-      }
-    }
+    for (int64_t bk = 0; bk < pl.B; ++bk) mark(pl.sblk_j[bk], pl.sblk_k[bk]);
   }
   return std::string();
 }

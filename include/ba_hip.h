@@ -101,7 +101,9 @@ int ba_partition_points(int n_pose, const uint8_t *pose_fixed, int n_pt,
 
 /* ---- multi-GPU exchange hook ------------------------------------------- */
 /* The caller owns the collective (RCCL through torch.distributed, or
- * anything else).  `which`: 0 = reduced camera system S||rhs, 1 = LM scalars.
+ * anything else).  `which`: 0 = reduced camera system, PACKED: the 36 entries
+ * of every structurally non-zero 6x6 block of S (global block numbering,
+ * identical on all shards) followed by the 6N entries of rhs; 1 = LM scalars.
  * The hook must sum-all-reduce n doubles at dev_ptr in place, ordered on
  * hip_stream. */
 typedef int (*ba_allreduce_fn)(void *user, int which, void *dev_ptr,
