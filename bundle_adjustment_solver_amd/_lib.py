@@ -102,6 +102,9 @@ SIGNATURES = {
     "ba_get_pairs": (C.c_int, [_P, _I32, _I32, _D]),
     "ba_get_S": (C.c_int, [_P, _D, _D]),
     "ba_get_xy": (C.c_int, [_P, _D, _D]),
+    "ba_kernel_count": (C.c_int, []),
+    "ba_kernel_name": (C.c_char_p, [C.c_int]),
+    "ba_get_kernel_ms": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int]),
     "ba_get_dense_info": (C.c_int, [_P, _D]),
     "ba_dense_spd_solve": (C.c_int, [_P, C.c_int, _D, _D, _D, _D]),
     "ba_pose_only_mono6": (C.c_int, [_P, _F, _F, C.c_int, C.c_float, C.c_float,

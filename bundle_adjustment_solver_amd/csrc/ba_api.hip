@@ -62,6 +62,7 @@ struct ba_handle {
   bool ev_ok = false;
   double stage_ms[ST_N] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool lm_begun = false;
+  ba::KernelTimer kt;        // per-kernel event timing (diagnostic mode)
   ba::DenseSchedule sched;   // level schedule of the reduced-system Cholesky
   ba::DenseDev ddev;
   std::vector<int> pose_col_h;
@@ -124,6 +125,7 @@ int xchg(ba_handle *h, int which) {
 int enqueue_iteration(ba_handle *h) {
   const ba::DevProblem &d = h->d;
   hipStream_t s = h->stream;
+  ba::g_ktimer = h->timing ? &h->kt : nullptr;
   mark(h, 0);
   ba::launch_linearize(d, s);
   mark(h, 1);
@@ -143,8 +145,10 @@ int enqueue_iteration(ba_handle *h) {
   mark(h, 7);
   ba::launch_control(d, s);
   mark(h, 8);
+  ba::g_ktimer = nullptr;
   if (h->timing) {
     HIP_TRY(hipStreamSynchronize(s));
+    h->kt.collect();
     static const int stage_of[8] = {ST_BUILD, ST_SCHUR, ST_XCHG,  ST_SOLVE,
                                     ST_BACKSUB, ST_COST, ST_XCHG, ST_CTRL};
     for (int k = 0; k < 8; ++k) {
@@ -691,6 +695,7 @@ int ba_enable_stage_timing(ba_handle *h, int on) {
     h->ev_ok = true;
   }
   h->timing = on != 0;
+  h->kt.on = h->timing;
   return 0;
 }
 
@@ -835,6 +840,27 @@ int ba_get_xy(ba_handle *h, double *x6, double *y3) {
 }
 
 // ---------------------------------------------------------------------------
+int ba_kernel_count(void) { return ba::K_COUNT; }
+
+const char *ba_kernel_name(int id) {
+  static const char *names[ba::K_COUNT] = {
+      "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
+      "k_schur_lds", "k_schur_partial", "k_rhs_final", "k_schur_final", "k_scatter",
+      "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_backsub_update",
+      "k_pose_update", "k_scalars", "k_control"};
+  return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
+}
+
+int ba_get_kernel_ms(ba_handle *h, double *ms_out, int64_t *calls_out, int reset) {
+  if (!h || !ms_out || !calls_out) return fail("ba_get_kernel_ms: bad argument");
+  for (int k = 0; k < ba::K_COUNT; ++k) {
+    ms_out[k] = h->kt.ms[k];
+    calls_out[k] = h->kt.calls[k];
+  }
+  if (reset) h->kt.reset();
+  return 0;
+}
+
 int ba_get_dense_info(ba_handle *h, double out4[4]) {
   if (!h || !h->finalized || !out4) return fail("ba_get_dense_info: bad argument");
   out4[0] = h->sched.fill;

@@ -369,7 +369,7 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
                        const int *zt_J, int n_zt, const int *done_flag,
                        hipStream_t s) {
   if (n_zt > 0)
-    hipLaunchKernelGGL(k_dense_init, dim3(n_zt), dim3(256), 0, s, L, ld, col_x,
+    BA_LAUNCH(K_DENSE_INIT, k_dense_init, dim3(n_zt), dim3(256), s, L, ld, col_x,
                        zt_I, zt_J, done_flag);
 }
 
@@ -382,20 +382,20 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   const int row_limit = npad + 16;  // rows that carry data (rhs = row npad)
   for (int l = 0; l < sc.nlev; ++l) {
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;
-    hipLaunchKernelGGL(k_chol_diag, dim3(nt), dim3(256), 0, s, L, ld, t0, Ldiag,
+    BA_LAUNCH(K_CHOL_DIAG, k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag,
                        done);
     const int it0 = sc.item_ptr[l], ni = sc.item_ptr[l + 1] - it0;
     if (ni > 0)
-      hipLaunchKernelGGL(k_chol_trsm, dim3(ni), dim3(256), 0, s, L, ld,
+      BA_LAUNCH(K_CHOL_TRSM, k_chol_trsm, dim3(ni), dim3(256), s, L, ld,
                          row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);
     const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0;
     if (ng > 0)
-      hipLaunchKernelGGL(k_chol_update, dim3(ng), dim3(256), 0, s, L, ld, tg0,
+      BA_LAUNCH(K_CHOL_UPDATE, k_chol_update, dim3(ng), dim3(256), s, L, ld, tg0,
                          dd.tgt_I, dd.tgt_J, dd.tgt_src_ptr, dd.src_t, done);
   }
   for (int l = sc.nlev - 1; l >= 0; --l) {
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;
-    hipLaunchKernelGGL(k_chol_back, dim3(nt), dim3(256), 0, s, L, ld, npad, t0,
+    BA_LAUNCH(K_CHOL_BACK, k_chol_back, dim3(nt), dim3(256), s, L, ld, npad, t0,
                        dd.row_ptr, dd.rows, Ldiag, dd.xc, x, dd.col_x, done);
   }
 }

@@ -133,6 +133,35 @@ constexpr int kDenseNb = 64;
 // dense workspace per 64-column block: L11 (64x64) + four 16x16 tile inverses
 constexpr int kDenseWsPerBlock = 64 * 64 + 4 * 256;
 
+// ---- optional per-kernel device timing (hipEvents around every launch) ----
+// Enabled by ba_enable_stage_timing: bench.py uses it to measure the average
+// launch duration of each kernel live, on the stream the kernels run on.
+enum KernelId {
+  K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
+  K_SCHUR_LDS, K_SCHUR_PARTIAL, K_RHS_FINAL, K_SCHUR_FINAL, K_SCATTER,
+  K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_BACKSUB_UPDATE,
+  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_COUNT
+};
+struct KernelTimer {
+  bool on = false;
+  std::vector<hipEvent_t> pool;          // grows on demand
+  std::vector<int> ids;                  // kernel id of span k (events 2k,2k+1)
+  double ms[K_COUNT] = {0};
+  long calls[K_COUNT] = {0};
+  void begin(int id, hipStream_t s);
+  void end(hipStream_t s);
+  void collect();                        // after a stream sync
+  void reset();
+};
+extern thread_local KernelTimer *g_ktimer;
+// launch a kernel, bracketed by events when a timer is installed
+#define BA_LAUNCH(id, kernel, grid, block, stream, ...)                     \
+  do {                                                                      \
+    if (::ba::g_ktimer && ::ba::g_ktimer->on) ::ba::g_ktimer->begin(id, stream); \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);        \
+    if (::ba::g_ktimer && ::ba::g_ktimer->on) ::ba::g_ktimer->end(stream);  \
+  } while (0)
+
 // ---- launchers (ba_kernels.hip) ----
 // sel: 0 = accepted parameters, 1 = trial parameters
 void launch_cost(const DevProblem &d, int sel, hipStream_t s);

@@ -19,6 +19,40 @@
 
 namespace ba {
 
+thread_local KernelTimer *g_ktimer = nullptr;
+
+void KernelTimer::begin(int id, hipStream_t s) {
+  const size_t k = ids.size();
+  while (pool.size() < 2 * (k + 1)) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    pool.push_back(e);
+  }
+  ids.push_back(id);
+  (void)hipEventRecord(pool[2 * k], s);
+}
+void KernelTimer::end(hipStream_t s) {
+  if (ids.empty()) return;
+  (void)hipEventRecord(pool[2 * (ids.size() - 1) + 1], s);
+}
+void KernelTimer::collect() {
+  for (size_t k = 0; k < ids.size(); ++k) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, pool[2 * k], pool[2 * k + 1]) == hipSuccess) {
+      ms[ids[k]] += t;
+      calls[ids[k]] += 1;
+    }
+  }
+  ids.clear();
+}
+void KernelTimer::reset() {
+  for (int k = 0; k < K_COUNT; ++k) {
+    ms[k] = 0;
+    calls[k] = 0;
+  }
+  ids.clear();
+}
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -1000,60 +1034,58 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 }  // namespace
 
 void launch_cost(const DevProblem &d, int sel, hipStream_t s) {
-  hipLaunchKernelGGL(k_cost, dim3(kCostGrid), dim3(kBlock), 0, s, d, sel);
+  BA_LAUNCH(K_COST, k_cost, dim3(kCostGrid), dim3(kBlock), s, d, sel);
 }
 
 void launch_linearize(const DevProblem &d, hipStream_t s) {
   if (d.n_bchunk > 0)
-    hipLaunchKernelGGL(k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), s, d);
   if (d.n_achunk > 0)
-    hipLaunchKernelGGL(k_lin_poses, dim3(d.n_achunk), dim3(kBlock), 0, s, d);
+    BA_LAUNCH(K_LIN_POSES, k_lin_poses, dim3(d.n_achunk), dim3(kBlock), s, d);
   if (d.N > 0)
-    hipLaunchKernelGGL(k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)),
-                       dim3(kBlock), 0, s, d);
+    BA_LAUNCH(K_POSE_FINALIZE, k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), s, d);
 }
 
 void launch_schur(const DevProblem &d, hipStream_t s) {
   launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, &d.ctrl->done, s);
   if (d.n_sup > 0)
-    hipLaunchKernelGGL(k_schur_lds, dim3(d.n_sup), dim3(kBlock), 0, s, d);
+    BA_LAUNCH(K_SCHUR_LDS, k_schur_lds, dim3(d.n_sup), dim3(kBlock), s, d);
   if (d.n_tchunk > 0)
-    hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
+    BA_LAUNCH(K_SCHUR_PARTIAL, k_schur_partial, dim3(d.n_tchunk), dim3(64), s, d);
   if (d.N > 0)
-    hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)),
-                       dim3(kBlock), 0, s, d);
+    BA_LAUNCH(K_RHS_FINAL, k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)), dim3(kBlock), s, d);
   if (d.B > 0)
-    hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s,
+    BA_LAUNCH(K_SCHUR_FINAL, k_schur_final, dim3((unsigned)d.B), dim3(kBlock), s,
                        d);
 }
 
 void launch_scatter(const DevProblem &d, hipStream_t s) {
   const int64_t n = d.B * 36 + 6 * (int64_t)d.N;
   if (n > 0)
-    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, s, d);
+    BA_LAUNCH(K_SCATTER, k_scatter, dim3(cdiv(n, kBlock)), dim3(kBlock), s, d);
 }
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s) {
   if (d.n_bchunk > 0)
-    hipLaunchKernelGGL(k_backsub_update, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
-  hipLaunchKernelGGL(k_pose_update, dim3(kPoseGrid), dim3(kBlock), 0, s, d);
+    BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(d.n_bchunk), dim3(kBlock), s, d);
+  BA_LAUNCH(K_POSE_UPDATE, k_pose_update, dim3(kPoseGrid), dim3(kBlock), s, d);
 }
 
 void launch_scalars(const DevProblem &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(kBlock), 0, s, d, 1);
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kBlock), s, d, 1);
 }
 
 void launch_control(const DevProblem &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, s, d);
+  BA_LAUNCH(K_CONTROL, k_control, dim3(1), dim3(64), s, d);
 }
 
 void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_ctrl_cost, dim3(1), dim3(64), 0, s, d);
+  BA_LAUNCH(K_CONTROL, k_init_ctrl_cost, dim3(1), dim3(64), s, d);
 }
 
 // exposed for ba_api: initial-cost scalar reduction (mode 0)
 void launch_scalars_cost_only(const DevProblem &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(kBlock), 0, s, d, 0);
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kBlock), s, d, 0);
 }
 
 }  // namespace ba

@@ -421,6 +421,17 @@ class BaProblem:
         check(self.lib.ba_get_xy(self.h, _dp(x), _dp(y)), "ba_get_xy")
         return x, y
 
+    def get_kernel_ms(self, reset=True):
+        """{kernel name: (total ms, launches)} accumulated in timing mode."""
+        n = self.lib.ba_kernel_count()
+        ms = np.zeros(n)
+        calls = np.zeros(n, np.int64)
+        check(self.lib.ba_get_kernel_ms(
+            self.h, _dp(ms), calls.ctypes.data_as(C.POINTER(C.c_int64)),
+            int(reset)), "ba_get_kernel_ms")
+        return {self.lib.ba_kernel_name(k).decode(): (float(ms[k]), int(calls[k]))
+                for k in range(n)}
+
     def get_dense_info(self):
         out = np.zeros(4)
         check(self.lib.ba_get_dense_info(self.h, _dp(out)),

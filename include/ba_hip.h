@@ -172,6 +172,13 @@ int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18);
 int ba_get_S(ba_handle *h, double *S, double *rhs);
 int ba_get_xy(ba_handle *h, double *x6, double *y3);
 
+/* Per-kernel device time (hipEvents around every launch, recorded on the
+ * handle's stream) accumulated while stage timing is enabled: total ms and
+ * number of launches per kernel id in [0, ba_kernel_count()). */
+int ba_kernel_count(void);
+const char *ba_kernel_name(int id);
+int ba_get_kernel_ms(ba_handle *h, double *ms_out, int64_t *calls_out, int reset);
+
 /* Structure of the reduced-system factorisation chosen at ba_finalize:
  * out4 = { non-zero tile fraction of the factor (1 = dense), executed flop
  * estimate per solve, number of elimination levels (launch depth), padded
