@@ -375,13 +375,16 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
 }
 
 // --------------------------------------------------------------------------
-// pose side of the linearisation: one block per chunk of one pose's
+// pose side of the linearisation: one wave per chunk of one pose's
 // observations -> 27 partial sums (21 upper A + 6 of Q^T w r)
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   if (d.ctrl->done) return;
-  __shared__ double sm[4];
-  const int ch = blockIdx.x;
+  // one WAVE per chunk (<= kPoseChunk observations of ONE pose): no block-level
+  // synchronisation, one 6-step shuffle reduction per accumulator at the end
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (ch >= d.n_achunk) return;
   const int buf = d.ctrl->cur;
   const double huber = d.ctrl->huber;
   const int j = d.achunk_pose[ch];
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
   const int64_t e = d.achunk_end[ch];
-  for (int64_t s = d.achunk_begin[ch] + threadIdx.x; s < e; s += kBlock) {
+  for (int64_t s = d.achunk_begin[ch] + lane; s < e; s += 64) {
     const int4 id = d.pobs_idx[s];
     const double2 uv = d.pobs_uv[s];
     const double *cam = d.cams + id.x * 16;
@@ -417,8 +420,8 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   }
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    const double tot = block_sum(acc[k], sm);
-    if (threadIdx.x == 0) d.Apart[(size_t)ch * 27 + k] = tot;
+    const double tot = wave_sum(acc[k]);
+    if (lane == 0) d.Apart[(size_t)ch * 27 + k] = tot;
   }
 }
 
@@ -1041,7 +1044,7 @@ void launch_linearize(const DevProblem &d, hipStream_t s) {
   if (d.n_bchunk > 0)
     BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), s, d);
   if (d.n_achunk > 0)
-    BA_LAUNCH(K_LIN_POSES, k_lin_poses, dim3(d.n_achunk), dim3(kBlock), s, d);
+    BA_LAUNCH(K_LIN_POSES, k_lin_poses, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d);
   if (d.N > 0)
     BA_LAUNCH(K_POSE_FINALIZE, k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), s, d);
 }

@@ -34,7 +34,7 @@ struct PlanInput {
 };
 
 // Work-item granularities (shared with the kernels).
-constexpr int kPoseChunk = 4096;   // observations per A/a partial-sum item
+constexpr int kPoseChunk = 1024;   // observations per A/a partial-sum item (one wave)
 constexpr int kRhsChunk = 1024;    // pairs per rhs partial-sum item
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
 constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
