@@ -507,12 +507,30 @@ constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
       const int t_ = tid + k_ * kBlock;                                       \
       rb[k_] = (t_ < (cd_).nl * 3) ? d.b[(size_t)(cd_).l0 * 3 + t_] : 0.0;    \
     }                                                                         \
-    rpl = (tid < (cd_).np) ? d.pair_lm[(cd_).p0 + tid] - (cd_).l0 : 0;        \
+    /* raw value: any arithmetic here would wait for every load above */      \
+    rpl = (tid < (cd_).np) ? d.pair_lm[(cd_).p0 + tid] : 0;                   \
     rsp = (tid <= ns) ? (int)d.chunk_sp[(cd_).sp + tid] : 0;                  \
   }
 
+__device__ __forceinline__ int64_t uni64(int64_t v) {  // wave-uniform value -> SGPRs
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+#ifdef BA_SCHUR_DBG
+__device__ long long g_schur_dbg[4][160];
+#define DBG_STAMP() { if (dbg_on && dbg_n < 160) g_schur_dbg[dbg_slot][dbg_n++] = clock64(); }
+#else
+#define DBG_STAMP()
+#endif
 __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   if (d.ctrl->done) return;
+#ifdef BA_SCHUR_DBG
+  const int dbg_slot = blockIdx.x == 10 ? 0 : blockIdx.x == 700 ? 1 : blockIdx.x == 1200 ? 2 : blockIdx.x == 1900 ? 3 : -1;
+  const bool dbg_on = dbg_slot >= 0 && threadIdx.x == 0;
+  int dbg_n = 0;
+  DBG_STAMP()
+#endif
   __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Vs[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Cs[kSchurLandmarks * 6];
@@ -520,25 +538,35 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   __shared__ uint32_t Ts[kSchurTri];
   __shared__ uint16_t Sp[kSchurSlots + 1];
   __shared__ uint16_t Pl[kSchurPairs];
+  __shared__ DevProblem::ChunkDesc Cdsc[kSchurSuperLandmarks];
   const int tid = threadIdx.x;
   const DevProblem::SupDesc sd = d.sup_desc[blockIdx.x];
   const int ns = sd.ns;
-  // lanes per slot: largest power of two with ns * tps <= 256, at most 32
-  int tps = 32;
-  while (tps * ns > kBlock) tps >>= 1;
-  const int slot = tid / tps, sub = tid - slot * tps;
-  const bool owner = slot < ns;
+  // slots are dealt to the four waves (spw per wave, never straddling one);
+  // every slot gets tps = 64 / spw lanes (at most 32, any value: the final
+  // reduction is a guarded shuffle-down tree)
+  const int spw = (ns + 3) >> 2;
+  const int tps = spw <= 2 ? 32 : 64 / spw;
+  const int lane = tid & 63;
+  const int sl = lane / tps, sub = lane - sl * tps;
+  const int slot = (tid >> 6) * spw + sl;
+  const bool owner = sl < spw && slot < ns;
   double acc[36], racc[6];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) racc[k] = 0.0;
+  // The run's chunk descriptors are staged in LDS once (vector loads): a scalar
+  // load inside the loop would share lgkmcnt with the LDS traffic and expose a
+  // full memory latency at the first LDS wait of every chunk.
   DevProblem::ChunkDesc cd = d.chunk_desc[sd.chunk_begin];
+  if (tid < sd.chunk_end - sd.chunk_begin) Cdsc[tid] = d.chunk_desc[sd.chunk_begin + tid];
   double2 rw[kSchurRW], rc[kSchurRC];
   uint32_t rt[kSchurRT];
   double rb[kSchurRB];
   int rpl, rsp;
   SCHUR_PREFETCH(cd)
+  __syncthreads();  // Cdsc visible
   for (int ch = sd.chunk_begin; ch < sd.chunk_end; ++ch) {
     // registers -> LDS
     {
@@ -564,26 +592,53 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
         const int t = tid + k * kBlock;
         if (t < cd.nl * 3) Bs[t] = rb[k];
       }
-      if (tid < cd.np) Pl[tid] = (uint16_t)rpl;
+      if (tid < cd.np) Pl[tid] = (uint16_t)(rpl - cd.l0);
       if (tid <= ns) Sp[tid] = (uint16_t)rsp;
     }
     const int np = cd.np;
+    DBG_STAMP()
     if (ch + 1 < sd.chunk_end) {  // next chunk's loads fly during this one
-      cd = d.chunk_desc[ch + 1];
+      const DevProblem::ChunkDesc *q = &Cdsc[ch + 1 - sd.chunk_begin];
+      cd.p0 = uni64(q->p0);
+      cd.tb = uni64(q->tb);
+      cd.sp = uni64(q->sp);
+      cd.l0 = __builtin_amdgcn_readfirstlane(q->l0);
+      cd.nl = __builtin_amdgcn_readfirstlane(q->nl);
+      cd.np = __builtin_amdgcn_readfirstlane(q->np);
+      cd.nt = __builtin_amdgcn_readfirstlane(q->nt);
       SCHUR_PREFETCH(cd)
     }
+    DBG_STAMP()
     __syncthreads();
+    DBG_STAMP()
     // V = W Cinv from LDS: one thread per (pair, row)
-    for (int t = tid; t < np * 6; t += kBlock) {
-      const int lp = t / 6;
-      const double *w = Ws + t * 3;
-      const double *ci = Cs + (int)Pl[lp] * 6;
-      const double w0 = w[0], w1 = w[1], w2 = w[2];
-      Vs[t * 3 + 0] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
-      Vs[t * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
-      Vs[t * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+    {
+      constexpr int kIt = (kSchurPairs * 6 + kBlock - 1) / kBlock;
+      double wv[kIt][3], cv[kIt][6];
+#pragma unroll
+      for (int k = 0; k < kIt; ++k) {  // all LDS reads first, then the arithmetic
+        const int t = tid + k * kBlock;
+        const bool on = t < np * 6;
+        const double *w = Ws + (on ? t : 0) * 3;
+        const double *ci = Cs + (on ? (int)Pl[t / 6] : 0) * 6;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) wv[k][e] = w[e];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) cv[k][e] = ci[e];
+      }
+#pragma unroll
+      for (int k = 0; k < kIt; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < np * 6) {
+          Vs[t * 3 + 0] = wv[k][0] * cv[k][0] + wv[k][1] * cv[k][1] + wv[k][2] * cv[k][2];
+          Vs[t * 3 + 1] = wv[k][0] * cv[k][1] + wv[k][1] * cv[k][3] + wv[k][2] * cv[k][4];
+          Vs[t * 3 + 2] = wv[k][0] * cv[k][2] + wv[k][1] * cv[k][4] + wv[k][2] * cv[k][5];
+        }
+      }
     }
+    DBG_STAMP()
     __syncthreads();
+    DBG_STAMP()
     if (owner) {
       const int t1 = (int)Sp[slot + 1];
       for (int t = (int)Sp[slot] + sub; t < t1; t += tps) {
@@ -614,28 +669,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
         }
       }
     }
+    DBG_STAMP()
     __syncthreads();  // LDS is rewritten by the next chunk
+    DBG_STAMP()
   }
-  // sum the tps lanes of every slot (fixed butterfly), store 288 B per slot
+  DBG_STAMP()
+  // sum the tps lanes of every slot: guarded shuffle-down tree (fixed order,
+  // any tps <= 32), result in the slot's first lane; 288 + 48 B stored per slot
 #pragma unroll
-  for (int k = 0; k < 36; ++k) {
-    double a2 = acc[k];
-    if (tps > 16) a2 += __shfl_xor(a2, 16, 64);
-    if (tps > 8) a2 += __shfl_xor(a2, 8, 64);
-    if (tps > 4) a2 += __shfl_xor(a2, 4, 64);
-    if (tps > 2) a2 += __shfl_xor(a2, 2, 64);
-    if (tps > 1) a2 += __shfl_xor(a2, 1, 64);
-    acc[k] = a2;
-  }
+  for (int k = 0; k < 42; ++k) {
+    double a2 = k < 36 ? acc[k] : racc[k - 36];
+    int w = tps;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    double a2 = racc[k];
-    if (tps > 16) a2 += __shfl_xor(a2, 16, 64);
-    if (tps > 8) a2 += __shfl_xor(a2, 8, 64);
-    if (tps > 4) a2 += __shfl_xor(a2, 4, 64);
-    if (tps > 2) a2 += __shfl_xor(a2, 2, 64);
-    if (tps > 1) a2 += __shfl_xor(a2, 1, 64);
-    racc[k] = a2;
+    for (int off = 16; off >= 1; off >>= 1) {
+      const double o2 = __shfl_down(a2, off, 64);
+      if (sub + off < w) a2 += o2;
+      w = w < off ? w : off;
+    }
+    if (k < 36) acc[k] = a2; else racc[k - 36] = a2;
   }
   if (owner && sub == 0) {
     double *o = d.spart2 + (size_t)(sd.s0 + slot) * kSlotStride;
@@ -1049,6 +1100,11 @@ void launch_linearize(const DevProblem &d, hipStream_t s) {
     BA_LAUNCH(K_POSE_FINALIZE, k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), s, d);
 }
 
+#ifdef BA_SCHUR_DBG
+extern "C" int ba_debug_read(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_dbg), sizeof(long long) * 4 * 160);
+}
+#endif
 void launch_schur(const DevProblem &d, hipStream_t s) {
   launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, &d.ctrl->done, s);
   if (d.n_sup > 0)
