@@ -395,6 +395,19 @@ int ba_finalize(ba_handle *h) {
   d.n_sup = (int)pl.sup_desc.size();
   d.n_bchunk = (int)pl.bchunk_lm.size() - 1;
   if (h->upload(&d.bchunk_lm, pl.bchunk_lm)) return -1;
+  {
+    std::vector<ba::DevProblem::LmChunk> lc((size_t)d.n_bchunk);
+    for (int c = 0; c < d.n_bchunk; ++c) {
+      const int l0 = pl.bchunk_lm[c], l1 = pl.bchunk_lm[c + 1];
+      lc[c].pb = pl.lm_pair_ptr[l0];
+      lc[c].ob = pl.lm_obs_ptr[l0];
+      lc[c].l0 = l0;
+      lc[c].nl = l1 - l0;
+      lc[c].np = (int32_t)(pl.lm_pair_ptr[l1] - pl.lm_pair_ptr[l0]);
+      lc[c].no = (int32_t)(pl.lm_obs_ptr[l1] - pl.lm_obs_ptr[l0]);
+    }
+    if (h->upload(&d.lm_chunk, lc)) return -1;
+  }
   d.n_slot = (int)pl.slot_blk.size();
   {
     static_assert(sizeof(ba::Plan::SupDesc) == sizeof(ba::DevProblem::SupDesc), "desc layout");
@@ -462,6 +475,7 @@ int ba_finalize(ba_handle *h) {
         h->upload(&dd.item_t, sc.item_t) || h->upload(&dd.item_I, sc.item_I) ||
         h->upload(&dd.tgt_I, sc.tgt_I) || h->upload(&dd.tgt_J, sc.tgt_J) ||
         h->upload(&dd.tgt_src_ptr, sc.tgt_src_ptr) || h->upload(&dd.src_t, sc.src_t) ||
+        h->upload(&dd.tgt_desc, sc.tgt_desc) || h->upload(&dd.back_desc, sc.back_desc) ||
         h->dalloc(&dd.xc, (size_t)d.npad))
       return -1;
     dd.col_x = d.col_x;
@@ -915,7 +929,8 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   };
   if (up(&dd.row_ptr, sc.row_ptr) || up(&dd.rows, sc.rows) || up(&dd.item_t, sc.item_t) ||
       up(&dd.item_I, sc.item_I) || up(&dd.tgt_I, sc.tgt_I) || up(&dd.tgt_J, sc.tgt_J) ||
-      up(&dd.tgt_src_ptr, sc.tgt_src_ptr) || up(&dd.src_t, sc.src_t) || up(&dd.col_x, col_x))
+      up(&dd.tgt_src_ptr, sc.tgt_src_ptr) || up(&dd.src_t, sc.src_t) || up(&dd.col_x, col_x) ||
+      up(&dd.tgt_desc, sc.tgt_desc) || up(&dd.back_desc, sc.back_desc))
     return -1;
   HIP_TRY(hipMalloc((void **)&dd.xc, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
@@ -937,7 +952,8 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   (void)hipEventDestroy(e1);
   for (void *p : {(void *)dL, (void *)dD, (void *)dx, (void *)dd.xc, (void *)dd.row_ptr,
                   (void *)dd.rows, (void *)dd.item_t, (void *)dd.item_I, (void *)dd.tgt_I,
-                  (void *)dd.tgt_J, (void *)dd.tgt_src_ptr, (void *)dd.src_t, (void *)dd.col_x})
+                  (void *)dd.tgt_J, (void *)dd.tgt_src_ptr, (void *)dd.src_t, (void *)dd.col_x,
+                  (void *)dd.tgt_desc, (void *)dd.back_desc})
     (void)hipFree(p);
   HIP_TRY(hipGetLastError());
   return 0;

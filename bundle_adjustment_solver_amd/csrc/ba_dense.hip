@@ -65,15 +65,19 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // 1/L_cc and is not stored).  A non-positive pivot zeroes its column.
 __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
   const int r = lane & 15, q = lane >> 4;
+  // Elimination with UNSCALED columns (LDL^T style): step c only needs 1/d_c
+  // (v_rcp_f64 + 2 Newton steps) on its dependent chain
+  //   G[r][c2] -= G[r][c] G[c2][c] / d_c.
+  // Column c is final after step c, so the 1/sqrt(d_c) scaling of all 16
+  // columns is done afterwards, four independent chains per lane, instead of
+  // one serial rsq chain inside every step.
+  bool okc[4] = {true, true, true, true};
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const int cq = c & 3, cj = c >> 2;
     const double d = readlane_f64(g[cj], c + 16 * cq);
     const bool ok = d > 1e-300;
     const double ds = ok ? d : 1.0;
-    // The dependent chain pivot -> update -> next pivot only needs 1/d
-    // (v_rcp_f64 + 2 Newton steps): G[r][c2] -= G[r][c] G[c2][c] / d with the
-    // UNSCALED column.  The 1/sqrt(d) scaling of column c is off the chain.
     double ri = __builtin_amdgcn_rcp(ds);
     ri = fma(fma(-ds, ri, 1.0), ri, ri);
     ri = fma(fma(-ds, ri, 1.0), ri, ri);
@@ -87,7 +91,15 @@ __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
       const bool upd = (c2 > c) && ((r <= c) || (c2 <= r));
       if (upd) g[j] = fma(-mr, lc, g[j]);
     }
-    // scale column c by 1/sqrt(d) (v_rsq_f64 + Newton), diagonal = sqrt(d)
+    if (q == cq) okc[cj] = ok;
+  }
+  // scale column c by 1/sqrt(d_c) (v_rsq_f64 + Newton), diagonal = sqrt(d_c)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * j + q;
+    const double d = __shfl(g[j], c + 16 * q, 64);  // pivot of this lane's column
+    const bool ok = okc[j];
+    const double ds = ok ? d : 1.0;
     double y = __builtin_amdgcn_rsq(ds);
     const double hd = 0.5 * ds;
 #pragma unroll
@@ -95,14 +107,23 @@ __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
     double sq = ds * y;
     sq = fma(fma(-sq, sq, ds), 0.5 * y, sq);
     y = fma(fma(-sq, y, 1.0), y, y);
-    if (q == cq) g[cj] = ok ? ((r == c) ? sq : g[cj] * y) : 0.0;
+    g[j] = ok ? ((r == c) ? sq : g[j] * y) : 0.0;
   }
 }
 
+#ifdef BA_DENSE_DBG
+__device__ long long g_dense_dbg[64];
+#define DD_STAMP() { if (threadIdx.x == 0 && blockIdx.x == 0 && t0 == 0 && dd_n < 64) g_dense_dbg[dd_n++] = clock64(); }
+#else
+#define DD_STAMP()
+#endif
 __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
                                                    int t0, double *ws_all,
                                                    const int *done) {
-  if (done && *done) return;
+#ifdef BA_DENSE_DBG
+  int dd_n = 0;
+#endif
+  DD_STAMP()
   // one workgroup per diagonal tile of the level (independent tiles)
   const int k0 = (t0 + blockIdx.x) * NB;
   double *ws = ws_all + (size_t)(t0 + blockIdx.x) * kDenseWsPerBlock;
@@ -112,12 +133,24 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
   __shared__ double Eb[4][16 * ES];   // Eb[p][k*ES + c] = E_pp[k][c]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  for (int e = tid; e < NB * NB; e += 256) {
+  // the block is requested before the `done` word is examined: one memory
+  // latency for both instead of two in a row
+  double lv[NB * NB / 256];
+#pragma unroll
+  for (int k = 0; k < NB * NB / 256; ++k) {
+    const int e = tid + 256 * k;
     const int c = e / NB, r = e % NB;
-    Lb[c * LS + r] = (r >= c) ? L[(size_t)(k0 + c) * ld + k0 + r] : 0.0;
+    lv[k] = (r >= c) ? L[(size_t)(k0 + c) * ld + k0 + r] : 0.0;
+  }
+  if (done && *done) return;
+#pragma unroll
+  for (int k = 0; k < NB * NB / 256; ++k) {
+    const int e = tid + 256 * k;
+    Lb[(e / NB) * LS + e % NB] = lv[k];
   }
   for (int e = tid; e < 4 * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
   __syncthreads();
+  DD_STAMP()
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     // (1) left-looking update of panel p: tile (ti,p) -= sum_kt L(ti,kt) L(p,kt)^T
@@ -139,6 +172,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
       }
       __syncthreads();
     }
+    DD_STAMP()
     // (2) factor the diagonal tile (wave 0)
     if (wv == 0) {
       const int r = lr, q = lk;
@@ -157,6 +191,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
         if (r == c) Eb[p][r * ES + c] = (g[j] > 0.0) ? 1.0 / g[j] : 0.0;
       }
     }
+    DD_STAMP()
     __syncthreads();
     // (3) TRSM of the tiles below: X = T * E_pp   (waves 1..3)
     if (p < 3) {
@@ -177,6 +212,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
       __syncthreads();
     }
   }
+  DD_STAMP()
   for (int e = tid; e < NB * NB; e += 256) {
     const int c = e / NB, r = e % NB;
     ws[e] = (r >= c) ? Lb[c * LS + r] : 0.0;
@@ -185,7 +221,13 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
     const int p = e >> 8, k = (e >> 4) & 15, c = e & 15;
     ws[NB * NB + e] = Eb[p][k * ES + c];
   }
+  DD_STAMP()
 }
+#ifdef BA_DENSE_DBG
+extern "C" int ba_debug_read_dense(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dense_dbg), sizeof(long long) * 64);
+}
+#endif
 
 // ---- step 2: TRSM of the rows below the diagonal block --------------------
 // X = A21 * L11^-T by block forward substitution over the four 16-column
@@ -201,7 +243,6 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
                                                    const int *__restrict__ item_I,
                                                    const double *__restrict__ ws_all,
                                                    const int *done) {
-  if (done && *done) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   // one workgroup per structurally non-zero 64-row tile (t, I) of the level
@@ -212,26 +253,48 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
   const double *ws = ws_all + (size_t)t * kDenseWsPerBlock;
   const double *Ld = ws;
   const double *Et = ws + NB * NB;
-  v4f64 X[4];
+  // every operand is requested up front (addresses depend only on the item),
+  // then the `done` word is examined: one memory latency for the whole kernel
+  v4f64 A0[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    v4f64 acc;
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      acc[g] = L[(size_t)(k0 + 16 * p + lk + 4 * g) * ld + r0 + lr];
+      A0[p][g] = L[(size_t)(k0 + 16 * p + lk + 4 * g) * ld + r0 + lr];
+  double ld_op[6][4], et_op[4][4];
+  {
+    int q = 0;
 #pragma unroll
-    for (int kq = 0; kq < p; ++kq)
+    for (int p = 1; p < 4; ++p)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const double a = -Ld[(16 * kq + lk + 4 * g) * NB + 16 * p + lr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[kq][g], acc, 0, 0, 0);
+      for (int kq = 0; kq < p; ++kq) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ld_op[q][g] = -Ld[(16 * kq + lk + 4 * g) * NB + 16 * p + lr];
+        ++q;
       }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) et_op[p][g] = Et[p * 256 + (lk + 4 * g) * 16 + lr];
+  if (done && *done) return;
+  v4f64 X[4];
+  int q = 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    v4f64 acc = A0[p];
+#pragma unroll
+    for (int kq = 0; kq < p; ++kq) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ld_op[q][g], X[kq][g], acc, 0, 0, 0);
+      ++q;
+    }
     v4f64 out = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const double a = Et[p * 256 + (lk + 4 * g) * 16 + lr];
-      out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[g], out, 0, 0, 0);
-    }
+    for (int g = 0; g < 4; ++g)
+      out = __builtin_amdgcn_mfma_f64_16x16x4f64(et_op[p][g], acc[g], out, 0, 0, 0);
     X[p] = out;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -248,25 +311,37 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
 // "column" index (lane&15) over C's ROW i, so that each accumulator register
 // is 16 consecutive rows of one column = 128 contiguous bytes in memory.
 __global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
-                                                     const int *__restrict__ tgt_I,
-                                                     const int *__restrict__ tgt_J,
-                                                     const int *__restrict__ tgt_src_ptr,
+                                                     const int *__restrict__ tgt_desc,
                                                      const int *__restrict__ src_t,
                                                      const int *done) {
-  if (done && *done) return;
   const int tg = tg0 + blockIdx.x;
-  const int I = tgt_I[tg], J = tgt_J[tg];
+  // inline record: I, J, nsrc, src_begin | first four sources
+  const int4 d0 = ((const int4 *)tgt_desc)[2 * tg];
+  const int4 d1 = ((const int4 *)tgt_desc)[2 * tg + 1];
+  const int dn = done ? *done : 0;
+  if (dn) return;
+  const int I = d0.x, J = d0.y, nsrc = d0.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = wv & 1, wj = wv >> 1;
   const int i0 = I * NB + 32 * wi, j0 = J * NB + 32 * wj;
   const int lr = lane & 15, lk = lane >> 4;
+  // the target tile is requested together with the first source panel
+  v4f64 tv[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        tv[m][n][g] = L[(size_t)(j0 + 16 * m + lk + 4 * g) * ld + i0 + 16 * n + lr];
   v4f64 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  for (int sidx = tgt_src_ptr[tg]; sidx < tgt_src_ptr[tg + 1]; ++sidx) {
-    const double *P = L + (size_t)src_t[sidx] * NB * ld;
+  for (int k = 0; k < nsrc; ++k) {
+    const int st = k == 0 ? d1.x : k == 1 ? d1.y : k == 2 ? d1.z : k == 3 ? d1.w : src_t[d0.w + k];
+    const double *P = L + (size_t)st * NB * ld;
 #pragma unroll 4
     for (int kk = 0; kk < NB / 4; ++kk) {
       const double *col = P + (size_t)(kk * 4 + lk) * ld;
@@ -286,8 +361,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
       for (int g = 0; g < 4; ++g) {
         const int j = j0 + 16 * m + lk + 4 * g;
         const int i = i0 + 16 * n + lr;
-        double *dst = L + (size_t)j * ld + i;
-        *dst -= acc[m][n][g];
+        L[(size_t)j * ld + i] = tv[m][n][g] - acc[m][n][g];
       }
 }
 
@@ -298,57 +372,83 @@ __global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
 // tile inverses:  x_p = E_pp (w_p - sum_{u>p} L_up^T x_u),  p = 3..0.
 __global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
                                                    int npad, int t0,
-                                                   const int *__restrict__ row_ptr,
+                                                   const int *__restrict__ back_desc,
                                                    const int *__restrict__ rows,
                                                    const double *__restrict__ ws_all,
                                                    double *xc, double *x,
                                                    const int *__restrict__ col_x,
                                                    const int *done) {
-  if (done && *done) return;
   __shared__ double xs[NB];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x;
   const int t = t0 + blockIdx.x;
   const int k0 = t * NB;
-  const int ncb = npad / NB;
+  // inline record: nrow, row_begin | first six row tiles
+  const int4 d0 = ((const int4 *)back_desc)[2 * t];
+  const int4 d1 = ((const int4 *)back_desc)[2 * t + 1];
+  const int dn = done ? *done : 0;
   const double *Ld = ws_all + (size_t)t * kDenseWsPerBlock;
   const double *Et = Ld + NB * NB;
+  // wave 0 needs, much later, operands whose addresses depend on nothing but t:
+  // they are requested now so that their latency hides behind the gather
+  const int i = tid & 15, q = (tid >> 4) & 3;
+  double lop[3][4][4];  // [p][u-1-p .. ][rr] for u > p
+  double eop[4][4], zv[4];
+  int xidx = -1;
+  if (tid < 64) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int u = p + 1; u < 4; ++u)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          lop[p][u - 1][rr] = Ld[(16 * p + i) * NB + 16 * u + 4 * q + rr];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) eop[p][cc] = Et[p * 256 + i * 16 + 4 * q + cc];
+      zv[p] = L[(size_t)(k0 + 16 * p + i) * ld + npad];
+    }
+    xidx = col_x[k0 + tid];
+  }
+  if (dn) return;
   {
-    const int c = tid & 63, q = tid >> 6;
+    const int c = tid & 63, qq = tid >> 6;
     const double *colp = L + (size_t)(k0 + c) * ld;
     double s = 0.0;
-    for (int a = row_ptr[t]; a < row_ptr[t + 1]; ++a) {
-      const int I = rows[a];
-      if (I >= ncb) break;  // the rhs row block closes the list
-      const double *src = colp + I * NB + 16 * q;
-      const double *xi = xc + I * NB + 16 * q;
+    const int nrow = d0.x;
+    for (int a = 0; a < nrow; ++a) {
+      const int I = a == 0 ? d0.z : a == 1 ? d0.w : a == 2 ? d1.x : a == 3 ? d1.y
+                  : a == 4 ? d1.z : a == 5 ? d1.w : rows[d0.y + a];
+      const double *src = colp + I * NB + 16 * qq;
+      const double *xi = xc + I * NB + 16 * qq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += src[r] * xi[r];
     }
-    part[q][c] = s;
+    part[qq][c] = s;
   }
   __syncthreads();
   if (tid < 64) {
-    const int i = tid & 15, q = tid >> 4;
 #pragma unroll
     for (int p = 3; p >= 0; --p) {
       double acc = 0.0;
+#pragma unroll
       for (int u = p + 1; u < 4; ++u)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = 16 * u + 4 * q + rr;
-          acc += Ld[(16 * p + i) * NB + row] * xs[row];
+          acc += lop[p < 3 ? p : 0][u - 1][rr] * xs[row];
         }
       acc += __shfl_xor(acc, 16, 64);
       acc += __shfl_xor(acc, 32, 64);
       const int c = 16 * p + i;
       const double below = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
-      const double wv = (L[(size_t)(k0 + c) * ld + npad] - below) - acc;
+      const double wv = (zv[p] - below) - acc;
       double px = 0.0;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int c2 = 4 * q + cc;
-        px += Et[p * 256 + i * 16 + c2] * __shfl(wv, c2, 64);
+        px += eop[p][cc] * __shfl(wv, c2, 64);
       }
       px += __shfl_xor(px, 16, 64);
       px += __shfl_xor(px, 32, 64);
@@ -358,8 +458,7 @@ __global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     xc[k0 + tid] = xs[tid];
-    const int xi = col_x[k0 + tid];
-    if (xi >= 0) x[xi] = xs[tid];
+    if (xidx >= 0) x[xidx] = xs[tid];
   }
 }
 
@@ -391,12 +490,12 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
     const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0;
     if (ng > 0)
       BA_LAUNCH(K_CHOL_UPDATE, k_chol_update, dim3(ng), dim3(256), s, L, ld, tg0,
-                         dd.tgt_I, dd.tgt_J, dd.tgt_src_ptr, dd.src_t, done);
+                         dd.tgt_desc, dd.src_t, done);
   }
   for (int l = sc.nlev - 1; l >= 0; --l) {
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;
     BA_LAUNCH(K_CHOL_BACK, k_chol_back, dim3(nt), dim3(256), s, L, ld, npad, t0,
-                       dd.row_ptr, dd.rows, Ldiag, dd.xc, x, dd.col_x, done);
+                       dd.back_desc, dd.rows, Ldiag, dd.xc, x, dd.col_x, done);
   }
 }
 

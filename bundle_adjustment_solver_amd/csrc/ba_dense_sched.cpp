@@ -134,6 +134,24 @@ void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj_in,
     s.tgt_ptr.push_back((int)s.tgt_I.size());
   }
   s.tgt_src_ptr.push_back((int)s.src_t.size());
+  s.tgt_desc.assign(8 * s.tgt_I.size(), -1);
+  for (size_t tg = 0; tg < s.tgt_I.size(); ++tg) {
+    int *q = &s.tgt_desc[8 * tg];
+    q[0] = s.tgt_I[tg];
+    q[1] = s.tgt_J[tg];
+    q[2] = s.tgt_src_ptr[tg + 1] - s.tgt_src_ptr[tg];
+    q[3] = s.tgt_src_ptr[tg];
+    for (int k = 0; k < 4 && k < q[2]; ++k) q[4 + k] = s.src_t[q[3] + k];
+  }
+  s.back_desc.assign(8 * (size_t)n, -1);
+  for (int p = 0; p < n; ++p) {
+    int *q = &s.back_desc[8 * (size_t)p];
+    int cnt = 0;
+    for (int a = s.row_ptr[p]; a < s.row_ptr[p + 1] && s.rows[a] < n; ++a) ++cnt;
+    q[0] = cnt;
+    q[1] = s.row_ptr[p];
+    for (int k = 0; k < 6 && k < cnt; ++k) q[2 + k] = s.rows[q[1] + k];
+  }
 }
 
 }  // namespace ba

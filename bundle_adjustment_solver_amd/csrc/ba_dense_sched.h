@@ -39,6 +39,11 @@ struct DenseSchedule {
   std::vector<int> item_ptr, item_t, item_I;        // TRSM items per level
   std::vector<int> tgt_ptr, tgt_I, tgt_J;           // update targets per level
   std::vector<int> tgt_src_ptr, src_t;              // sources of each target
+  // The same lists as fixed 8-int records, so that a workgroup reaches its data
+  // after ONE dependent load:
+  //   tgt_desc[8 tg ..] = { I, J, nsrc, src_begin, first four sources (-1 pad) }
+  //   back_desc[8 p ..] = { nrow (without the rhs block), row_begin, first six rows }
+  std::vector<int> tgt_desc, back_desc;
   double fill = 1.0;        // non-zero factor tiles / all lower tiles
   double flops = 0.0;       // executed flops of factor + solves (estimate)
 };

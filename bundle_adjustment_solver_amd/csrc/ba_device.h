@@ -120,6 +120,13 @@ struct DevProblem {
   int *pose_col;   // N: first dense column of optimised pose j
   int *col_x;      // npad: dense column -> 6*pose + r, or -1 (padding)
   int32_t *bchunk_lm;  // n_bchunk+1 landmark ranges (backsub)
+  // the same chunks as one 32-byte record each, so that a workgroup knows its
+  // landmark / pair / observation ranges after ONE dependent load
+  struct LmChunk {
+    int64_t pb, ob;           // first pair, first (landmark-major) observation
+    int32_t l0, nl, np, no;   // first landmark, #landmarks, #pairs, #observations
+  };
+  LmChunk *lm_chunk;   // n_bchunk
   int n_bchunk;
   int *zt_I, *zt_J;  // tiles of L that are (re)initialised every iteration
   int n_zt;
@@ -183,6 +190,7 @@ struct DenseDev {
   int *item_t = nullptr, *item_I = nullptr;      // TRSM items
   int *tgt_I = nullptr, *tgt_J = nullptr;        // update targets
   int *tgt_src_ptr = nullptr, *src_t = nullptr;  // their source panels
+  int *tgt_desc = nullptr, *back_desc = nullptr; // 8-int inline records
   int *col_x = nullptr;   // npad: column -> index into x (6*pose + r) or -1
   double *xc = nullptr;   // npad: solution in column order
 };

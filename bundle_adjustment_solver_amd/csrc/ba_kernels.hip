@@ -78,6 +78,29 @@ __device__ __forceinline__ double block_sum(double v, double *sm) {
   return r;
 }
 
+// The camera table (16 doubles per camera: fx fy cx cy, R_cj row-major, t_cj)
+// is read by every observation: the first kCamLds cameras live in LDS so the
+// per-observation gather does not go to the vector memory pipeline.
+constexpr int kCamLds = 8;
+__device__ __forceinline__ void stage_cams(const DevProblem &d, double *cams_s) {
+  const int n = (d.n_cam < kCamLds ? d.n_cam : kCamLds) * 16;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) cams_s[k] = d.cams[k];
+}
+// LDSCAM is a kernel template parameter (chosen at launch: n_cam <= kCamLds),
+// not a run-time branch: a divergent fallback inside a pipelined loop makes the
+// compiler drain every outstanding load at the join.
+template <bool LDSCAM>
+__device__ __forceinline__ void load_cam(const DevProblem &d, const double *cams_s,
+                                         int idx, double cam[16]) {
+  if (LDSCAM) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cam[k] = cams_s[idx * 16 + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cam[k] = d.cams[(size_t)idx * 16 + k];
+  }
+}
+
 // Projection of one observation; reference :743-760 / :413-425.
 struct ObsGeom {
   double Xij[3];
@@ -237,22 +260,76 @@ __device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
 // --------------------------------------------------------------------------
 // cost: sum over observations of ||r||  (reference :381-433)
 // --------------------------------------------------------------------------
+// Grid-stride over observations, software-pipelined: while observation s is
+// projected, the gathered pose / point of s+stride and the record of
+// s+2*stride are in flight.  The pose/point registers ping-pong (loop unrolled
+// by two) and the record registers are reloaded right after their last use, so
+// no register move ever has to wait for a load issued in the same step.
+#define COST_STEP(TC, XC, TN, XN)                                               \
+  {                                                                             \
+    /* gathers of the next observation (record arrived one step ago) */         \
+    const double *Tp_ = poses + (size_t)idn.y * 12;                             \
+    const double *Xp_ = pts + (size_t)idn.z * 3;                                \
+    _Pragma("unroll") for (int k_ = 0; k_ < 12; ++k_) TN[k_] = Tp_[k_];         \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) XN[k_] = Xp_[k_];          \
+    const int ncam_ = idn.x;                                                    \
+    const double2 nuv_ = uvn;                                                   \
+    /* record two strides ahead, into the registers just read (clamped, not  */ \
+    /* conditional: a join after a conditional load waits for it)            */ \
+    {                                                                           \
+      const int64_t s2_ = s + 2 * stride < d.n_obs ? s + 2 * stride : d.n_obs - 1; \
+      idn = d.obs_idx[s2_];                                                     \
+      uvn = d.obs_uv[s2_];                                                      \
+    }                                                                           \
+    ObsGeom g_;                                                                 \
+    double cam_[16];                                                            \
+    load_cam<LDSCAM>(d, cams_s, ccam, cam_);                                    \
+    project(cam_, TC, XC[0], XC[1], XC[2], cuv.x, cuv.y, g_);                   \
+    acc += sqrt(g_.r0 * g_.r0 + g_.r1 * g_.r1);                                 \
+    ccam = ncam_;                                                               \
+    cuv = nuv_;                                                                 \
+  }
+
+template <bool LDSCAM>
 __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
-  if (d.ctrl->done) return;
   __shared__ double sm[4];
+  __shared__ double cams_s[kCamLds * 16];
+  if (LDSCAM) stage_cams(d, cams_s);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // first record issued before the control word is needed
+  int4 id0 = make_int4(0, 0, 0, 0);
+  double2 cuv = make_double2(0.0, 0.0);
+  if (s < d.n_obs) {
+    id0 = d.obs_idx[s];
+    cuv = d.obs_uv[s];
+  }
+  if (d.ctrl->done) return;
   const int buf = d.ctrl->cur ^ sel;
   const double *__restrict__ poses = d.poses[buf];
   const double *__restrict__ pts = d.pts[buf];
+  // past-the-end prefetches are clamped to the last record: harmless gathers
+  const int64_t s1 = s + stride < d.n_obs ? s + stride : d.n_obs - 1;
+  int4 idn = d.obs_idx[s1];
+  double2 uvn = d.obs_uv[s1];
+  double TA[12], XA[3], TB[12], XB[3];
+  {
+    const double *Tp = poses + (size_t)id0.y * 12;
+    const double *Xp = pts + (size_t)id0.z * 3;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) TA[k] = Tp[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) XA[k] = Xp[k];
+  }
+  int ccam = id0.x;
   double acc = 0.0;
-  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < d.n_obs;
-       s += (int64_t)gridDim.x * kBlock) {
-    const int4 id = d.obs_idx[s];
-    const double2 uv = d.obs_uv[s];
-    const double *X = pts + (size_t)id.z * 3;
-    ObsGeom g;
-    project(d.cams + id.x * 16, poses + (size_t)id.y * 12, X[0], X[1], X[2],
-            uv.x, uv.y, g);
-    acc += sqrt(g.r0 * g.r0 + g.r1 * g.r1);
+  __syncthreads();  // cams_s
+  while (s < d.n_obs) {
+    COST_STEP(TA, XA, TB, XB)
+    s += stride;
+    if (s >= d.n_obs) break;
+    COST_STEP(TB, XB, TA, XA)
+    s += stride;
   }
   const double tot = block_sum(acc, sm);
   if (threadIdx.x == 0) d.cost_part[blockIdx.x] = tot;
@@ -814,36 +891,94 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
 // tile): the W blocks are copied to LDS with contiguous 16-byte loads, lane
 // (pair, c) forms u_c = sum_r W[r][c] x_j[r], then one thread per landmark sums
 // its pairs and finishes y, the trial point and the model terms.
+// Dependent-load chain per workgroup: chunk record -> {W, pose indices, the
+// landmarks' own data} -> x_j gather; everything of one level is issued together.
+#define BACKSUB_ISSUE(t0_, np_)                                                 \
+  {                                                                             \
+    const double2 *src_ = (const double2 *)(d.W + (size_t)(t0_) * 18);          \
+    _Pragma("unroll") for (int k_ = 0; k_ < kBsRW; ++k_) {                      \
+      const int t_ = tid + k_ * kBlock;                                         \
+      rw[k_] = (t_ < (np_) * 9) ? src_[t_] : make_double2(0.0, 0.0);            \
+    }                                                                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < kBsRX; ++k_) {                      \
+      const int t_ = tid + k_ * kBlock;                                         \
+      rpj[k_] = (t_ < (np_) * 3) ? d.pair_pose[(t0_) + t_ / 3] : 0;             \
+    }                                                                           \
+  }
+constexpr int kBsRW = (kSchurPairs * 9 + kBlock - 1) / kBlock;
+constexpr int kBsRX = (kSchurPairs * 3 + kBlock - 1) / kBlock;
+
 __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
-  if (d.ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
+  __shared__ __attribute__((aligned(16))) double Xs[kSchurPairs * 6];
   __shared__ double Us[kSchurPairs * 3];
   __shared__ double sm[4];
-  const int tid = threadIdx.x;
+  const DevProblem::LmChunk lc = d.lm_chunk[blockIdx.x];
+  const int done = d.ctrl->done;
   const int cur = d.ctrl->cur;
+  if (done) return;
+  const int tid = threadIdx.x;
   const double *__restrict__ Xc = d.pts[cur];
   double *__restrict__ Xt = d.pts[cur ^ 1];
-  const int l0 = d.bchunk_lm[blockIdx.x], l1 = d.bchunk_lm[blockIdx.x + 1];
-  const int64_t pb = d.lm_pair_ptr[l0], pe = d.lm_pair_ptr[l1];
-  const int i = l0 + tid;  // landmark owned by this thread (if any)
-  const bool own = i < l1;
+  const int64_t pe = lc.pb + lc.np;
+  int64_t t0 = lc.pb;
+  int np = lc.np < kSchurPairs ? lc.np : kSchurPairs;
+  double2 rw[kBsRW];
+  int rpj[kBsRX];
+  BACKSUB_ISSUE(t0, np)
+  // the landmark owned by this thread (if any): its data is needed last but
+  // depends only on the chunk record, so it is requested now
+  const int i = lc.l0 + tid;
+  const bool own = tid < lc.nl;
   int64_t q0 = 0, q1 = 0;
+  double ci[6], cb[3], Xi[3], bi[3], C[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ci[k] = C[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cb[k] = Xi[k] = bi[k] = 0.0;
   if (own) {
     q0 = d.lm_pair_ptr[i];
     q1 = d.lm_pair_ptr[i + 1];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ci[k] = d.Cinv[(size_t)i * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cb[k] = d.Cinvb[(size_t)i * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Xi[k] = Xc[(size_t)i * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bi[k] = d.b[(size_t)i * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C[k] = d.Cd[(size_t)i * 6 + k];
   }
   double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
-  for (int64_t t0 = pb; t0 < pe; t0 += kSchurPairs) {
-    const int np = (int)min((int64_t)kSchurPairs, pe - t0);
+  for (;;) {
+    // x_j gather: lane (pair, c) fetches x_j[2c], x_j[2c+1]
+    double2 rx[kBsRX];
+#pragma unroll
+    for (int k = 0; k < kBsRX; ++k) {
+      const int t = tid + k * kBlock;
+      const int c = t - (t / 3) * 3;
+      rx[k] = (t < np * 3) ? *(const double2 *)(d.x + (size_t)rpj[k] * 6 + 2 * c)
+                           : make_double2(0.0, 0.0);
+    }
     {
-      const double2 *src = (const double2 *)(d.W + (size_t)t0 * 18);
       double2 *dst = (double2 *)Ws;
-      for (int t = tid; t < np * 9; t += kBlock) dst[t] = src[t];
+#pragma unroll
+      for (int k = 0; k < kBsRW; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < np * 9) dst[t] = rw[k];
+      }
+      double2 *xd = (double2 *)Xs;
+#pragma unroll
+      for (int k = 0; k < kBsRX; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < np * 3) xd[t] = rx[k];
+      }
     }
     __syncthreads();
     for (int t = tid; t < np * 3; t += kBlock) {
       const int lp = t / 3, c = t - lp * 3;
-      const double *xj = d.x + (size_t)d.pair_pose[t0 + lp] * 6;
+      const double *xj = Xs + lp * 6;
       const double *w = Ws + lp * 18 + c;
       double u = 0.0;
 #pragma unroll
@@ -860,25 +995,24 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
         bx2 += u[2];
       }
     }
-    __syncthreads();
+    t0 += kSchurPairs;
+    if (t0 >= pe) break;  // uniform
+    np = (int)min((int64_t)kSchurPairs, pe - t0);
+    __syncthreads();  // LDS is rewritten
+    BACKSUB_ISSUE(t0, np)
   }
   double est = 0.0, nrm = 0.0;
   if (own) {
-    const double *ci = d.Cinv + (size_t)i * 6;
-    const double *cb = d.Cinvb + (size_t)i * 3;
     const double y0 = cb[0] - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);
     const double y1 = cb[1] - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);
     const double y2 = cb[2] - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);
     double *yo = d.y + (size_t)i * 3;
     yo[0] = y0; yo[1] = y1; yo[2] = y2;
-    const double *Xi = Xc + (size_t)i * 3;
     double *Xo = Xt + (size_t)i * 3;
     Xo[0] = Xi[0] + y0;
     Xo[1] = Xi[1] + y1;
     Xo[2] = Xi[2] + y2;
     // reference :443-452 with the damped C_i
-    const double *bi = d.b + (size_t)i * 3;
-    const double *C = d.Cd + (size_t)i * 6;
     double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;
     const double r0 = y0 * C[0] + y1 * C[1] + y2 * C[2];
     const double r1 = y0 * C[1] + y1 * C[3] + y2 * C[4];
@@ -1088,7 +1222,10 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 }  // namespace
 
 void launch_cost(const DevProblem &d, int sel, hipStream_t s) {
-  BA_LAUNCH(K_COST, k_cost, dim3(kCostGrid), dim3(kBlock), s, d, sel);
+  if (d.n_cam <= kCamLds)
+    BA_LAUNCH(K_COST, k_cost<true>, dim3(kCostGrid), dim3(kBlock), s, d, sel);
+  else
+    BA_LAUNCH(K_COST, k_cost<false>, dim3(kCostGrid), dim3(kBlock), s, d, sel);
 }
 
 void launch_linearize(const DevProblem &d, hipStream_t s) {
