@@ -42,6 +42,12 @@ struct ba_handle {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // second stream for work that is independent inside one LM iteration
+  // (pose-side linearisation beside the landmark side + Schur accumulation;
+  // pose update beside the back-substitution), joined with events
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;
   // host copies of the problem (scaled units)
   int n_cam = 0, n_pose = 0, n_pt = 0;
   int64_t n_obs = 0;
@@ -126,17 +132,27 @@ int enqueue_iteration(ba_handle *h) {
   const ba::DevProblem &d = h->d;
   hipStream_t s = h->stream;
   ba::g_ktimer = h->timing ? &h->kt : nullptr;
+  // per-kernel / per-stage timing needs the serial order on one stream
+  const bool ov = h->overlap && !h->timing;
   mark(h, 0);
-  ba::launch_linearize(d, s);
-  mark(h, 1);
-  ba::launch_schur(d, s);
+  if (ov) {
+    ba::launch_linearize_schur_overlapped(d, s, h->side_stream, h->ev_fork, h->ev_join);
+    mark(h, 1);
+  } else {
+    ba::launch_linearize(d, s);
+    mark(h, 1);
+    ba::launch_schur(d, s);
+  }
   mark(h, 2);
   if (xchg(h, 0)) return -1;
   mark(h, 3);
   ba::launch_scatter(d, s);
   ba::launch_dense_solve(d, h->sched, h->ddev, s);
   mark(h, 4);
-  ba::launch_backsub_update(d, s);
+  if (ov)
+    ba::launch_backsub_update_overlapped(d, s, h->side_stream, h->ev_fork, h->ev_join);
+  else
+    ba::launch_backsub_update(d, s);
   mark(h, 5);
   ba::launch_cost(d, 1, s);
   ba::launch_scalars(d, s);
@@ -200,11 +216,15 @@ int ba_create(ba_handle **out, int device_id) {
   ba_handle *h = new ba_handle();
   h->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess ||
-      hipStreamCreate(&h->own_stream) != hipSuccess) {
+      hipStreamCreate(&h->own_stream) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete h;
     return fail("ba_create: cannot create stream");
   }
   h->stream = h->own_stream;
+  if (const char *e2 = getenv("BA_NO_OVERLAP")) h->overlap = !(e2[0] == '1');
   std::memset(&h->d, 0, sizeof(h->d));
   std::memset(&h->hc, 0, sizeof(h->hc));
   *out = h;
@@ -218,6 +238,12 @@ void ba_destroy(ba_handle *h) {
   h->free_device();
   if (h->ev_ok)
     for (int k = 0; k <= ST_N; ++k) (void)hipEventDestroy(h->ev[k]);
+  if (h->side_stream) {
+    (void)hipStreamSynchronize(h->side_stream);
+    (void)hipStreamDestroy(h->side_stream);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -343,7 +369,6 @@ int ba_finalize(ba_handle *h) {
   d.n_obs_opt = pl.n_obs_opt; d.n_obs_global = pl.n_obs_global; d.P = pl.P;
   d.n_pobs = pl.n_pobs; d.T = pl.T; d.B = pl.B;
   d.n_achunk = (int)pl.achunk_pose.size();
-  d.n_rchunk = (int)pl.rchunk_pose.size();
   d.n_tchunk = (int)pl.tchunk_blk.size();
 
   // parameters
@@ -382,9 +407,7 @@ int ba_finalize(ba_handle *h) {
       h->upload(&d.pair_pose, pl.pair_pose) || h->upload(&d.pair_lm, pl.pair_lm) ||
       h->upload(&d.achunk_pose, pl.achunk_pose) || h->upload(&d.achunk_begin, pl.achunk_begin) ||
       h->upload(&d.achunk_end, pl.achunk_end) || h->upload(&d.pose_achunk_ptr, pl.pose_achunk_ptr) ||
-      h->upload(&d.ppair, pl.ppair) || h->upload(&d.rchunk_pose, pl.rchunk_pose) ||
-      h->upload(&d.rchunk_begin, pl.rchunk_begin) || h->upload(&d.rchunk_end, pl.rchunk_end) ||
-      h->upload(&d.pose_rchunk_ptr, pl.pose_rchunk_ptr) || h->upload(&d.sblk_j, pl.sblk_j) || h->upload(&d.diag_blk, pl.diag_blk) ||
+      h->upload(&d.sblk_j, pl.sblk_j) || h->upload(&d.diag_blk, pl.diag_blk) ||
       h->upload(&d.sblk_k, pl.sblk_k) || h->upload(&d.tri_p, pl.tri_p) ||
       h->upload(&d.tri_q, pl.tri_q) || h->upload(&d.tchunk_blk, pl.tchunk_blk) ||
       h->upload(&d.tchunk_begin, pl.tchunk_begin) || h->upload(&d.tchunk_end, pl.tchunk_end) ||
@@ -428,7 +451,7 @@ int ba_finalize(ba_handle *h) {
       h->dalloc(&d.Cinv, (size_t)pl.M * 6) || h->dalloc(&d.Cinvb, (size_t)pl.M * 3) ||
       h->dalloc(&d.W, (size_t)pl.P * 18) ||
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) || h->dalloc(&d.A, (size_t)pl.N * 36) ||
-      h->dalloc(&d.a, (size_t)pl.N * 6) || h->dalloc(&d.rpart, (size_t)d.n_rchunk * 6) ||
+      h->dalloc(&d.a, (size_t)pl.N * 6) ||
       h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
       h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
       h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_bchunk) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||

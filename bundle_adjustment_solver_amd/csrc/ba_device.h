@@ -42,7 +42,7 @@ struct DevProblem {
   // sizes
   int n_cam, n_pose, N, n_pt, M, M_global;
   int64_t n_obs, n_obs_opt, n_obs_global, P, n_pobs, T, B;
-  int n_achunk, n_rchunk, n_tchunk;
+  int n_achunk, n_tchunk;
   // parameters: two buffers each (accepted / trial), selected by ctrl->cur
   double *cams;      // n_cam*16: fx fy cx cy R9 t3
   double *poses[2];  // n_pose*12
@@ -61,10 +61,6 @@ struct DevProblem {
   int64_t *achunk_begin, *achunk_end;
   int32_t *pose_achunk_ptr;
   // pose-major pairs
-  int64_t *ppair;
-  int32_t *rchunk_pose;
-  int64_t *rchunk_begin, *rchunk_end;
-  int32_t *pose_rchunk_ptr;
   // Schur structure
   int32_t *sblk_j, *sblk_k;
   int32_t *diag_blk;
@@ -97,7 +93,6 @@ struct DevProblem {
   double *Apart;   // n_achunk*27
   double *A;       // N*36  damped, full
   double *a;       // N*6
-  double *rpart;   // n_rchunk*6
   double *spart;   // n_tchunk*kSlotStride
   double *x;       // 6N
   double *y;       // M*3
@@ -174,6 +169,13 @@ extern thread_local KernelTimer *g_ktimer;
 void launch_cost(const DevProblem &d, int sel, hipStream_t s);
 void launch_linearize(const DevProblem &d, hipStream_t s);
 void launch_schur(const DevProblem &d, hipStream_t s);
+// two-stream forms of linearize+schur and backsub+update (see ba_kernels.hip)
+void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
+                                       hipStream_t s2, hipEvent_t fork,
+                                       hipEvent_t join);
+void launch_backsub_update_overlapped(const DevProblem &d, hipStream_t s,
+                                      hipStream_t s2, hipEvent_t fork,
+                                      hipEvent_t join);
 void launch_backsub_update(const DevProblem &d, hipStream_t s);
 void launch_scatter(const DevProblem &d, hipStream_t s);
 void launch_scalars(const DevProblem &d, hipStream_t s);

@@ -455,45 +455,89 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
 // pose side of the linearisation: one wave per chunk of one pose's
 // observations -> 27 partial sums (21 upper A + 6 of Q^T w r)
 // --------------------------------------------------------------------------
+// Software-pipelined like k_cost: the record of observation s+128 and the
+// gathered point of s+64 are in flight while s is processed.
+#define LINP_STEP(XC, XN)                                                       \
+  {                                                                             \
+    const double *Xp_ = pts + (size_t)idn.z * 3;                                \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) XN[k_] = Xp_[k_];          \
+    const int ncam_ = idn.x;                                                    \
+    const double2 nuv_ = uvn;                                                   \
+    {                                                                           \
+      const int64_t s2_ = s + 128 < e ? s + 128 : e - 1;                        \
+      idn = d.pobs_idx[s2_];                                                    \
+      uvn = d.pobs_uv[s2_];                                                     \
+    }                                                                           \
+    double cam_[16];                                                            \
+    load_cam<LDSCAM>(d, cams_s, ccam, cam_);                                    \
+    ObsGeom g;                                                                  \
+    project(cam_, Tl, XC[0], XC[1], XC[2], cuv.x, cuv.y, g);                    \
+    double w, G[6], Q[12];                                                      \
+    weight_and_G(cam_, g, huber, w, G);                                         \
+    make_Q(G, g.Xij, Q);                                                        \
+    /* reference :519-556 */                                                    \
+    int k = 0;                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 6; ++r)                               \
+    _Pragma("unroll") for (int c = r; c < 6; ++c)                               \
+      acc[k++] += (w * Q[r]) * Q[c] + (w * Q[6 + r]) * Q[6 + c];                \
+    const double wr0 = w * g.r0, wr1 = w * g.r1;                                \
+    _Pragma("unroll") for (int c = 0; c < 6; ++c)                               \
+      acc[21 + c] += Q[c] * wr0 + Q[6 + c] * wr1;                               \
+    ccam = ncam_;                                                               \
+    cuv = nuv_;                                                                 \
+  }
+
+template <bool LDSCAM>
 __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
-  if (d.ctrl->done) return;
-  // one WAVE per chunk (<= kPoseChunk observations of ONE pose): no block-level
-  // synchronisation, one 6-step shuffle reduction per accumulator at the end
+  // one WAVE per chunk (observations of ONE pose, see kPoseWaveTarget): no block-level
+  // synchronisation in the loop, one 6-step shuffle reduction per accumulator
+  // at the end
+  __shared__ double cams_s[kCamLds * 16];
+  if (LDSCAM) stage_cams(d, cams_s);
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (ch >= d.n_achunk) return;
+  const bool live = ch < d.n_achunk;
+  const int chc = live ? ch : 0;
+  // chunk record and control word requested together
+  const int64_t b = d.achunk_begin[chc], e = d.achunk_end[chc];
+  const int j = d.achunk_pose[chc];
+  const int done = d.ctrl->done;
   const int buf = d.ctrl->cur;
   const double huber = d.ctrl->huber;
-  const int j = d.achunk_pose[ch];
+  __syncthreads();  // cams_s
+  if (done || !live || b >= e) {
+    if (!done && live) {  // empty chunk: zero partial sums
+      for (int k = lane; k < 27; k += 64) d.Apart[(size_t)ch * 27 + k] = 0.0;
+    }
+    return;
+  }
   const double *__restrict__ pts = d.pts[buf];
   const double *T = d.poses[buf] + (size_t)j * 12;
+  int64_t s = b + lane;
+  const int64_t s0c = s < e ? s : e - 1, s1c = s + 64 < e ? s + 64 : e - 1;
+  const int4 id0 = d.pobs_idx[s0c];
+  double2 cuv = d.pobs_uv[s0c];
+  int4 idn = d.pobs_idx[s1c];
+  double2 uvn = d.pobs_uv[s1c];
   double Tl[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) Tl[k] = T[k];
+  double XA[3], XB[3];
+  {
+    const double *Xp = pts + (size_t)id0.z * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) XA[k] = Xp[k];
+  }
+  int ccam = id0.x;
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-  const int64_t e = d.achunk_end[ch];
-  for (int64_t s = d.achunk_begin[ch] + lane; s < e; s += 64) {
-    const int4 id = d.pobs_idx[s];
-    const double2 uv = d.pobs_uv[s];
-    const double *cam = d.cams + id.x * 16;
-    const double *X = pts + (size_t)id.z * 3;
-    ObsGeom g;
-    project(cam, Tl, X[0], X[1], X[2], uv.x, uv.y, g);
-    double w, G[6], Q[12];
-    weight_and_G(cam, g, huber, w, G);
-    make_Q(G, g.Xij, Q);
-    // reference :519-556
-    int k = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = r; c < 6; ++c)
-        acc[k++] += (w * Q[r]) * Q[c] + (w * Q[6 + r]) * Q[6 + c];
-    const double wr0 = w * g.r0, wr1 = w * g.r1;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) acc[21 + c] += Q[c] * wr0 + Q[6 + c] * wr1;
+  while (s < e) {
+    LINP_STEP(XA, XB)
+    s += 64;
+    if (s >= e) break;
+    LINP_STEP(XB, XA)
+    s += 64;
   }
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
@@ -1232,7 +1276,12 @@ void launch_linearize(const DevProblem &d, hipStream_t s) {
   if (d.n_bchunk > 0)
     BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), s, d);
   if (d.n_achunk > 0)
-    BA_LAUNCH(K_LIN_POSES, k_lin_poses, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d);
+  {
+    if (d.n_cam <= kCamLds)
+      BA_LAUNCH(K_LIN_POSES, k_lin_poses<true>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d);
+    else
+      BA_LAUNCH(K_LIN_POSES, k_lin_poses<false>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d);
+  }
   if (d.N > 0)
     BA_LAUNCH(K_POSE_FINALIZE, k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), s, d);
 }
@@ -1253,6 +1302,49 @@ void launch_schur(const DevProblem &d, hipStream_t s) {
   if (d.B > 0)
     BA_LAUNCH(K_SCHUR_FINAL, k_schur_final, dim3((unsigned)d.B), dim3(kBlock), s,
                        d);
+}
+
+// linearisation + Schur complement with the pose side on a second stream: the
+// pose-side sums (A_j, a_j) and the reset of the factor tiles depend only on
+// the current parameters and are first needed by k_rhs_final / k_schur_final,
+// so they run beside k_lin_landmarks and k_schur_lds instead of after them.
+void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
+                                       hipStream_t s2, hipEvent_t fork,
+                                       hipEvent_t join) {
+  (void)hipEventRecord(fork, s);
+  (void)hipStreamWaitEvent(s2, fork, 0);
+  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, &d.ctrl->done, s2);
+  if (d.n_achunk > 0) {
+    if (d.n_cam <= kCamLds)
+      hipLaunchKernelGGL(k_lin_poses<true>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), 0, s2, d);
+    else
+      hipLaunchKernelGGL(k_lin_poses<false>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), 0, s2, d);
+  }
+  if (d.N > 0)
+    hipLaunchKernelGGL(k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), 0, s2, d);
+  (void)hipEventRecord(join, s2);
+  if (d.n_bchunk > 0)
+    hipLaunchKernelGGL(k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+  if (d.n_sup > 0) hipLaunchKernelGGL(k_schur_lds, dim3(d.n_sup), dim3(kBlock), 0, s, d);
+  if (d.n_tchunk > 0)
+    hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
+  (void)hipStreamWaitEvent(s, join, 0);
+  if (d.N > 0)
+    hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)), dim3(kBlock), 0, s, d);
+  if (d.B > 0) hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s, d);
+}
+
+// back-substitution with the pose update (needs x only) on the second stream
+void launch_backsub_update_overlapped(const DevProblem &d, hipStream_t s,
+                                      hipStream_t s2, hipEvent_t fork,
+                                      hipEvent_t join) {
+  (void)hipEventRecord(fork, s);
+  (void)hipStreamWaitEvent(s2, fork, 0);
+  hipLaunchKernelGGL(k_pose_update, dim3(kPoseGrid), dim3(kBlock), 0, s2, d);
+  (void)hipEventRecord(join, s2);
+  if (d.n_bchunk > 0)
+    hipLaunchKernelGGL(k_backsub_update, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+  (void)hipStreamWaitEvent(s, join, 0);
 }
 
 void launch_scatter(const DevProblem &d, hipStream_t s) {

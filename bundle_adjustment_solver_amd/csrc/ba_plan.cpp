@@ -78,10 +78,17 @@ void make_chunks(const std::vector<int64_t> &ptr, int n_seg, int chunk,
   c_end.clear();
   seg_cptr.assign(n_seg + 1, 0);
   for (int s = 0; s < n_seg; ++s) {
-    for (int64_t b = ptr[s]; b < ptr[s + 1]; b += chunk) {
-      c_seg.push_back(s);
-      c_begin.push_back(b);
-      c_end.push_back(std::min<int64_t>(b + chunk, ptr[s + 1]));
+    const int64_t len = ptr[s + 1] - ptr[s];
+    if (len > 0) {
+      // equal pieces (multiples of 64 so that a wave's last step is full)
+      const int64_t nc = (len + chunk - 1) / chunk;
+      int64_t piece = (len + nc - 1) / nc;
+      piece = std::min<int64_t>((piece + 63) / 64 * 64, chunk);
+      for (int64_t b = ptr[s]; b < ptr[s + 1]; b += piece) {
+        c_seg.push_back(s);
+        c_begin.push_back(b);
+        c_end.push_back(std::min<int64_t>(b + piece, ptr[s + 1]));
+      }
     }
     seg_cptr[s + 1] = (int32_t)c_seg.size();
   }
@@ -239,20 +246,13 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       pl.pobs_uv[2 * d + 0] = pl.obs_uv[2 * s + 0];
       pl.pobs_uv[2 * d + 1] = pl.obs_uv[2 * s + 1];
     }
-    make_chunks(pl.pose_obs_ptr, N, kPoseChunk, pl.achunk_pose,
+    // one wave per chunk: aim at ~kPoseWaveTarget waves in total (one resident
+    // round on the GPU), each pose's list split into equal chunks
+    int64_t cap = (pl.n_pobs + kPoseWaveTarget - 1) / kPoseWaveTarget;
+    cap = (cap + 63) / 64 * 64;
+    cap = std::min<int64_t>(std::max<int64_t>(cap, kPoseChunkMin), kPoseChunkMax);
+    make_chunks(pl.pose_obs_ptr, N, (int)cap, pl.achunk_pose,
                 pl.achunk_begin, pl.achunk_end, pl.pose_achunk_ptr);
-  }
-
-  // ---- pose-major pair permutation ----
-  {
-    std::vector<int64_t> pptr(N + 1, 0);
-    for (int64_t p = 0; p < pl.P; ++p) pptr[pl.pair_pose[p] + 1]++;
-    for (int j = 0; j < N; ++j) pptr[j + 1] += pptr[j];
-    pl.ppair.resize(pl.P);
-    std::vector<int64_t> cur(pptr.begin(), pptr.end() - 1);
-    for (int64_t p = 0; p < pl.P; ++p) pl.ppair[cur[pl.pair_pose[p]]++] = p;
-    make_chunks(pptr, N, kRhsChunk, pl.rchunk_pose, pl.rchunk_begin,
-                pl.rchunk_end, pl.pose_rchunk_ptr);
   }
 
   // ---- Schur complement structure ----

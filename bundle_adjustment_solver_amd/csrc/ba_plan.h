@@ -34,8 +34,10 @@ struct PlanInput {
 };
 
 // Work-item granularities (shared with the kernels).
-constexpr int kPoseChunk = 1024;   // observations per A/a partial-sum item (one wave)
-constexpr int kRhsChunk = 1024;    // pairs per rhs partial-sum item
+// observations per A/a partial-sum item (one wave): chosen at finalize so that
+// about kPoseWaveTarget waves cover all observations
+constexpr int kPoseChunkMin = 256, kPoseChunkMax = 4096;
+constexpr int kPoseWaveTarget = 8192;
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
 constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
 constexpr int kSchurLandmarks = 128;  // landmarks per chunk
@@ -85,10 +87,6 @@ struct Plan {
   std::vector<int64_t> achunk_end;
   std::vector<int32_t> pose_achunk_ptr;  // N+1
   // ---- pose-major pair permutation ----
-  std::vector<int64_t> ppair;            // P pair ids sorted by (pose, lm)
-  std::vector<int32_t> rchunk_pose;
-  std::vector<int64_t> rchunk_begin, rchunk_end;
-  std::vector<int32_t> pose_rchunk_ptr;  // N+1
   // ---- Schur triples ----
   std::vector<int32_t> sblk_j, sblk_k;   // B
   std::vector<int32_t> diag_blk;         // N: block id of (j,j)
