@@ -348,35 +348,51 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
 //   pseudo-inverse) and stores Cd, b, Cinv, Cinv b.
 // The W image is written back with contiguous 16-byte stores.
 // --------------------------------------------------------------------------
+template <bool LDSCAM>
 __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
-  if (d.ctrl->done) return;
   __shared__ __attribute__((aligned(16))) double Wst[kSchurPairs * 18];
   __shared__ double Cb[kBlock * 9];
-  const int tid = threadIdx.x;
+  __shared__ double cams_s[kCamLds * 16];
+  // dependent-load chain: chunk record (+ control word) -> observation records
+  // (+ this thread's landmark range) -> pose / point gathers
+  const DevProblem::LmChunk lc = d.lm_chunk[blockIdx.x];
+  const int done = d.ctrl->done;
   const int buf = d.ctrl->cur;
   const double huber = d.ctrl->huber;
   const double lp1 = 1.0 + d.ctrl->lambda;
-  const double *__restrict__ poses = d.poses[buf];
-  const double *__restrict__ pts = d.pts[buf];
-  const int l0 = d.bchunk_lm[blockIdx.x], l1 = d.bchunk_lm[blockIdx.x + 1];
-  const int64_t pb = d.lm_pair_ptr[l0];
-  const int npair = (int)(d.lm_pair_ptr[l1] - pb);
-  const int64_t ob = d.lm_obs_ptr[l0], oe = d.lm_obs_ptr[l1];
-  const int i = l0 + tid;
-  const bool own = i < l1;
+  if (LDSCAM) stage_cams(d, cams_s);
+  const int tid = threadIdx.x;
+  const int64_t pb = lc.pb;
+  const int npair = lc.np;
+  const int64_t ob = lc.ob, oe = lc.ob + lc.no;
+  int4 id = make_int4(0, 0, 0, -1);
+  double2 uv = make_double2(0.0, 0.0);
+  if (tid < lc.no) {
+    id = d.obs_idx[ob + tid];
+    uv = d.obs_uv[ob + tid];
+  }
+  const int i = lc.l0 + tid;
+  const bool own = tid < lc.nl;
   int64_t q0 = 0, q1 = 0;
   if (own) {
     q0 = d.lm_obs_ptr[i];
     q1 = d.lm_obs_ptr[i + 1];
   }
+  if (done) return;
+  const double *__restrict__ poses = d.poses[buf];
+  const double *__restrict__ pts = d.pts[buf];
   double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
   double b0 = 0, b1 = 0, b2 = 0;
+  __syncthreads();  // cams_s
   for (int64_t t0 = ob; t0 < oe; t0 += kBlock) {
     const int64_t s = t0 + tid;
+    if (t0 > ob && s < oe) {  // further tiles (more than kBlock observations)
+      id = d.obs_idx[s];
+      uv = d.obs_uv[s];
+    }
     if (s < oe) {
-      const int4 id = d.obs_idx[s];
-      const double2 uv = d.obs_uv[s];
-      const double *cam = d.cams + id.x * 16;
+      double cam[16];
+      load_cam<LDSCAM>(d, cams_s, id.x, cam);
       const double *T = poses + (size_t)id.y * 12;
       const double *X = pts + (size_t)id.z * 3;
       ObsGeom g;
@@ -1274,7 +1290,12 @@ void launch_cost(const DevProblem &d, int sel, hipStream_t s) {
 
 void launch_linearize(const DevProblem &d, hipStream_t s) {
   if (d.n_bchunk > 0)
-    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), s, d);
+  {
+    if (d.n_cam <= kCamLds)
+      BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<true>, dim3(d.n_bchunk), dim3(kBlock), s, d);
+    else
+      BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<false>, dim3(d.n_bchunk), dim3(kBlock), s, d);
+  }
   if (d.n_achunk > 0)
   {
     if (d.n_cam <= kCamLds)
@@ -1324,7 +1345,12 @@ void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
     hipLaunchKernelGGL(k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), 0, s2, d);
   (void)hipEventRecord(join, s2);
   if (d.n_bchunk > 0)
-    hipLaunchKernelGGL(k_lin_landmarks, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+  {
+    if (d.n_cam <= kCamLds)
+      hipLaunchKernelGGL(k_lin_landmarks<true>, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+    else
+      hipLaunchKernelGGL(k_lin_landmarks<false>, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+  }
   if (d.n_sup > 0) hipLaunchKernelGGL(k_schur_lds, dim3(d.n_sup), dim3(kBlock), 0, s, d);
   if (d.n_tchunk > 0)
     hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
