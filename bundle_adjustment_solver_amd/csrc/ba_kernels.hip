@@ -655,14 +655,17 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {  // wave-uniform value -> 
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 #ifdef BA_SCHUR_DBG
+// developer instrumentation (tools/schur_dbg.py): phase time stamps of four
+// workgroups, kept in LDS during the run and copied out at the end
 __device__ long long g_schur_dbg[4][160];
-#define DBG_STAMP() { if (dbg_on && dbg_n < 160) g_schur_dbg[dbg_slot][dbg_n++] = clock64(); }
+#define DBG_STAMP() { if (dbg_on && dbg_n < 160) dbg_s[dbg_n++] = clock64(); }
 #else
 #define DBG_STAMP()
 #endif
 __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   if (d.ctrl->done) return;
 #ifdef BA_SCHUR_DBG
+  __shared__ long long dbg_s[160];
   const int dbg_slot = blockIdx.x == 10 ? 0 : blockIdx.x == 700 ? 1 : blockIdx.x == 1200 ? 2 : blockIdx.x == 1900 ? 3 : -1;
   const bool dbg_on = dbg_slot >= 0 && threadIdx.x == 0;
   int dbg_n = 0;
@@ -679,14 +682,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   const int tid = threadIdx.x;
   const DevProblem::SupDesc sd = d.sup_desc[blockIdx.x];
   const int ns = sd.ns;
-  // slots are dealt to the four waves (spw per wave, never straddling one);
+  // slots are dealt to the four waves (at most spw per wave, never straddling one);
   // every slot gets tps = 64 / spw lanes (at most 32, any value: the final
   // reduction is a guarded shuffle-down tree)
   const int spw = (ns + 3) >> 2;
   const int tps = spw <= 2 ? 32 : 64 / spw;
   const int lane = tid & 63;
   const int sl = lane / tps, sub = lane - sl * tps;
-  const int slot = (tid >> 6) * spw + sl;
+  // slot ids follow the block order, i.e. the position along the run: dealing
+  // them round-robin keeps all four waves busy in every chunk
+  const int slot = sl * 4 + (tid >> 6);
   const bool owner = sl < spw && slot < ns;
   double acc[36], racc[6];
 #pragma unroll
@@ -825,6 +830,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
     }
     if (k < 36) acc[k] = a2; else racc[k - 36] = a2;
   }
+#ifdef BA_SCHUR_DBG
+  if (dbg_on)
+    for (int k = 0; k < 160; ++k) g_schur_dbg[dbg_slot][k] = k < dbg_n ? dbg_s[k] : 0;
+#endif
   if (owner && sub == 0) {
     double *o = d.spart2 + (size_t)(sd.s0 + slot) * kSlotStride;
 #pragma unroll
