@@ -21,7 +21,10 @@ namespace ba {
 
 namespace {
 
-constexpr int NB = kDenseNb;  // 64
+constexpr int NB = kDenseNb;   // tile order (32 or 64)
+constexpr int NP = NB / 16;    // 16-column panels per tile
+static_assert(NB == 32 || NB == 64, "tile order");
+static_assert(kDenseWsPerBlock == NB * NB + NP * 256, "workspace layout");
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // (Re)initialise the tiles of L that the factorisation touches: the
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
   constexpr int LS = NB + 1;
   constexpr int ES = 17;
   __shared__ double Lb[NB * LS];      // Lb[c*LS + r]
-  __shared__ double Eb[4][16 * ES];   // Eb[p][k*ES + c] = E_pp[k][c]
+  __shared__ double Eb[NP][16 * ES];  // Eb[p][k*ES + c] = E_pp[k][c]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   // the block is requested before the `done` word is examined: one memory
@@ -148,15 +151,15 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
     const int e = tid + 256 * k;
     Lb[(e / NB) * LS + e % NB] = lv[k];
   }
-  for (int e = tid; e < 4 * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
+  for (int e = tid; e < NP * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
   __syncthreads();
   DD_STAMP()
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     // (1) left-looking update of panel p: tile (ti,p) -= sum_kt L(ti,kt) L(p,kt)^T
     if (p > 0) {
       const int ti = p + wv;
-      if (ti < 4) {
+      if (ti < NP) {
         v4f64 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -194,9 +197,9 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
     DD_STAMP()
     __syncthreads();
     // (3) TRSM of the tiles below: X = T * E_pp   (waves 1..3)
-    if (p < 3) {
+    if (p < NP - 1) {
       const int ti = p + wv;
-      if (wv >= 1 && ti < 4) {
+      if (wv >= 1 && ti < NP) {
         v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
     const int c = e / NB, r = e % NB;
     ws[e] = (r >= c) ? Lb[c * LS + r] : 0.0;
   }
-  for (int e = tid; e < 4 * 256; e += 256) {
+  for (int e = tid; e < NP * 256; e += 256) {
     const int p = e >> 8, k = (e >> 4) & 15, c = e & 15;
     ws[NB * NB + e] = Eb[p][k * ES + c];
   }
@@ -237,15 +240,15 @@ extern "C" int ba_debug_read_dense(long long *out) {
 // consecutive rows of one column (128 contiguous bytes), and — because the
 // f64 C/D map is row = (lane>>4) + 4*reg — the accumulator of one product is
 // already the B operand of the next (k-step g <-> k = (lane>>4) + 4g).
-__global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
+__global__ __launch_bounds__(NP * 64) void k_chol_trsm(double *L, int ld,
                                                    int row_limit, int it0,
                                                    const int *__restrict__ item_t,
                                                    const int *__restrict__ item_I,
                                                    const double *__restrict__ ws_all,
                                                    const int *done) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // NP waves
   const int lr = lane & 15, lk = lane >> 4;
-  // one workgroup per structurally non-zero 64-row tile (t, I) of the level
+  // one workgroup per structurally non-zero NB-row tile (t, I) of the level
   const int t = item_t[it0 + blockIdx.x];
   const int k0 = t * NB;
   const int r0 = item_I[it0 + blockIdx.x] * NB + 16 * wv;
@@ -255,17 +258,17 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
   const double *Et = ws + NB * NB;
   // every operand is requested up front (addresses depend only on the item),
   // then the `done` word is examined: one memory latency for the whole kernel
-  v4f64 A0[4];
+  v4f64 A0[NP];
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       A0[p][g] = L[(size_t)(k0 + 16 * p + lk + 4 * g) * ld + r0 + lr];
-  double ld_op[6][4], et_op[4][4];
+  double ld_op[NP * (NP - 1) / 2][4], et_op[NP][4];
   {
     int q = 0;
 #pragma unroll
-    for (int p = 1; p < 4; ++p)
+    for (int p = 1; p < NP; ++p)
 #pragma unroll
       for (int kq = 0; kq < p; ++kq) {
 #pragma unroll
@@ -275,14 +278,14 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
       }
   }
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int g = 0; g < 4; ++g) et_op[p][g] = Et[p * 256 + (lk + 4 * g) * 16 + lr];
   if (done && *done) return;
-  v4f64 X[4];
+  v4f64 X[NP];
   int q = 0;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     v4f64 acc = A0[p];
 #pragma unroll
     for (int kq = 0; kq < p; ++kq) {
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double *L, int ld,
 // MFMA orientation: the MFMA "row" index runs over C's COLUMN j and the MFMA
 // "column" index (lane&15) over C's ROW i, so that each accumulator register
 // is 16 consecutive rows of one column = 128 contiguous bytes in memory.
+constexpr int MT = NB / 32;  // 16x16 MFMA tiles per wave and dimension
 __global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
                                                      const int *__restrict__ tgt_desc,
                                                      const int *__restrict__ src_t,
@@ -323,40 +327,46 @@ __global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
   const int I = d0.x, J = d0.y, nsrc = d0.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = wv & 1, wj = wv >> 1;
-  const int i0 = I * NB + 32 * wi, j0 = J * NB + 32 * wj;
+  // four waves, each a (NB/2) x (NB/2) quadrant of the target tile
+  const int i0 = I * NB + (NB / 2) * wi, j0 = J * NB + (NB / 2) * wj;
   const int lr = lane & 15, lk = lane >> 4;
   // the target tile is requested together with the first source panel
-  v4f64 tv[2][2];
+  v4f64 tv[MT][MT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < MT; ++n)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         tv[m][n][g] = L[(size_t)(j0 + 16 * m + lk + 4 * g) * ld + i0 + 16 * n + lr];
-  v4f64 acc[2][2];
+  v4f64 acc[MT][MT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < MT; ++n) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
   for (int k = 0; k < nsrc; ++k) {
     const int st = k == 0 ? d1.x : k == 1 ? d1.y : k == 2 ? d1.z : k == 3 ? d1.w : src_t[d0.w + k];
     const double *P = L + (size_t)st * NB * ld;
 #pragma unroll 4
     for (int kk = 0; kk < NB / 4; ++kk) {
       const double *col = P + (size_t)(kk * 4 + lk) * ld;
-      const double a0 = col[j0 + lr], a1 = col[j0 + 16 + lr];
-      const double b0 = col[i0 + lr], b1 = col[i0 + 16 + lr];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      double av[MT], bv[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        av[m] = col[j0 + 16 * m + lr];
+        bv[m] = col[i0 + 16 * m + lr];
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < MT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < MT; ++n)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int j = j0 + 16 * m + lk + 4 * g;
@@ -370,6 +380,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
 // over the non-zero row tiles I below t (all solved in earlier launches), then
 // wave 0 solves the 64x64 diagonal system by block back substitution with the
 // tile inverses:  x_p = E_pp (w_p - sum_{u>p} L_up^T x_u),  p = 3..0.
+constexpr int BG = 256 / NB;  // row groups of the gather (each NB/BG rows)
+constexpr int BR = NB / BG;
 __global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
                                                    int npad, int t0,
                                                    const int *__restrict__ back_desc,
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
                                                    const int *__restrict__ col_x,
                                                    const int *done) {
   __shared__ double xs[NB];
-  __shared__ double part[4][NB];
+  __shared__ double part[BG][NB];
   const int tid = threadIdx.x;
   const int t = t0 + blockIdx.x;
   const int k0 = t * NB;
@@ -392,57 +404,59 @@ __global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
   // wave 0 needs, much later, operands whose addresses depend on nothing but t:
   // they are requested now so that their latency hides behind the gather
   const int i = tid & 15, q = (tid >> 4) & 3;
-  double lop[3][4][4];  // [p][u-1-p .. ][rr] for u > p
-  double eop[4][4], zv[4];
+  double lop[NP][NP][4];  // [p][u][rr], u > p
+  double eop[NP][4], zv[NP];
   int xidx = -1;
   if (tid < 64) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int u = p + 1; u < 4; ++u)
+      for (int u = p + 1; u < NP; ++u)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-          lop[p][u - 1][rr] = Ld[(16 * p + i) * NB + 16 * u + 4 * q + rr];
+          lop[p][u][rr] = Ld[(16 * p + i) * NB + 16 * u + 4 * q + rr];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) eop[p][cc] = Et[p * 256 + i * 16 + 4 * q + cc];
       zv[p] = L[(size_t)(k0 + 16 * p + i) * ld + npad];
     }
-    xidx = col_x[k0 + tid];
+    if (tid < NB) xidx = col_x[k0 + tid];
   }
   if (dn) return;
   {
-    const int c = tid & 63, qq = tid >> 6;
+    const int c = tid % NB, qq = tid / NB;
     const double *colp = L + (size_t)(k0 + c) * ld;
     double s = 0.0;
     const int nrow = d0.x;
     for (int a = 0; a < nrow; ++a) {
       const int I = a == 0 ? d0.z : a == 1 ? d0.w : a == 2 ? d1.x : a == 3 ? d1.y
                   : a == 4 ? d1.z : a == 5 ? d1.w : rows[d0.y + a];
-      const double *src = colp + I * NB + 16 * qq;
-      const double *xi = xc + I * NB + 16 * qq;
+      const double *src = colp + I * NB + BR * qq;
+      const double *xi = xc + I * NB + BR * qq;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += src[r] * xi[r];
+      for (int r = 0; r < BR; ++r) s += src[r] * xi[r];
     }
     part[qq][c] = s;
   }
   __syncthreads();
   if (tid < 64) {
 #pragma unroll
-    for (int p = 3; p >= 0; --p) {
+    for (int p = NP - 1; p >= 0; --p) {
       double acc = 0.0;
 #pragma unroll
-      for (int u = p + 1; u < 4; ++u)
+      for (int u = p + 1; u < NP; ++u)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = 16 * u + 4 * q + rr;
-          acc += lop[p < 3 ? p : 0][u - 1][rr] * xs[row];
+          acc += lop[p][u][rr] * xs[row];
         }
       acc += __shfl_xor(acc, 16, 64);
       acc += __shfl_xor(acc, 32, 64);
       const int c = 16 * p + i;
-      const double below = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+      double below = part[0][c];
+#pragma unroll
+      for (int g = 1; g < BG; ++g) below += part[g][c];
       const double wv = (zv[p] - below) - acc;
       double px = 0.0;
 #pragma unroll
@@ -457,8 +471,10 @@ __global__ __launch_bounds__(256) void k_chol_back(const double *L, int ld,
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    xc[k0 + tid] = xs[tid];
-    if (xidx >= 0) x[xidx] = xs[tid];
+    if (tid < NB) {
+      xc[k0 + tid] = xs[tid];
+      if (xidx >= 0) x[xidx] = xs[tid];
+    }
   }
 }
 
@@ -485,7 +501,7 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                        done);
     const int it0 = sc.item_ptr[l], ni = sc.item_ptr[l + 1] - it0;
     if (ni > 0)
-      BA_LAUNCH(K_CHOL_TRSM, k_chol_trsm, dim3(ni), dim3(256), s, L, ld,
+      BA_LAUNCH(K_CHOL_TRSM, k_chol_trsm, dim3(ni), dim3(NP * 64), s, L, ld,
                          row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);
     const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0;
     if (ng > 0)
