@@ -26,7 +26,7 @@
 
 namespace ba {
 
-constexpr int kPosesPerTile = 10;  // 60 columns + 4 padding columns per tile
+constexpr int kPosesPerTile = 5;  // 30 columns + 2 padding columns per tile
 
 struct DenseSchedule {
   int ncb = 0;    // tiles (the rhs row block has index ncb)

@@ -131,9 +131,9 @@ constexpr int kCostGrid = 1024;
 constexpr int kLmGrid = 1024;
 constexpr int kPoseGrid = 16;
 constexpr int kSlotStride = 42;  // 6x6 block of B Cinv B^T + 6 of B Cinv b
-constexpr int kDenseNb = 64;
+constexpr int kDenseNb = 32;
 // dense workspace per 64-column block: L11 (64x64) + four 16x16 tile inverses
-constexpr int kDenseWsPerBlock = 64 * 64 + 4 * 256;
+constexpr int kDenseWsPerBlock = kDenseNb * kDenseNb + (kDenseNb / 16) * 256;
 
 // ---- optional per-kernel device timing (hipEvents around every launch) ----
 // Enabled by ba_enable_stage_timing: bench.py uses it to measure the average
