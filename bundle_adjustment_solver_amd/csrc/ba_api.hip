@@ -518,6 +518,10 @@ int ba_finalize(ba_handle *h) {
         h->upload(&dd.tgt_desc, sc.tgt_desc) || h->upload(&dd.back_desc, sc.back_desc) ||
         h->dalloc(&dd.xc, (size_t)d.npad))
       return -1;
+    if (sc.fused_ok &&
+        (h->upload(&dd.f_desc, sc.f_desc) || h->upload(&dd.f_pend, sc.f_pend) ||
+         h->dalloc(&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * ba::kDenseNb * ba::kDenseNb)))
+      return -1;
     dd.col_x = d.col_x;
     HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
     // tiles (re)initialised per iteration: factor pattern + diagonal + rhs row
@@ -929,7 +933,7 @@ const char *ba_kernel_name(int id) {
   static const char *names[ba::K_COUNT] = {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
       "k_schur_lds", "k_schur_partial", "k_rhs_final", "k_schur_final", "k_scatter",
-      "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_backsub_update",
+      "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_backsub_update",
       "k_pose_update", "k_scalars", "k_control"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
 }
@@ -1001,6 +1005,11 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
       up(&dd.tgt_src_ptr, sc.tgt_src_ptr) || up(&dd.src_t, sc.src_t) || up(&dd.col_x, col_x) ||
       up(&dd.tgt_desc, sc.tgt_desc) || up(&dd.back_desc, sc.back_desc))
     return -1;
+  if (sc.fused_ok) {
+    if (up(&dd.f_desc, sc.f_desc) || up(&dd.f_pend, sc.f_pend)) return -1;
+    HIP_TRY(hipMalloc((void **)&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * ba::kDenseNb *
+                                             ba::kDenseNb * sizeof(double)));
+  }
   HIP_TRY(hipMalloc((void **)&dd.xc, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dD, (size_t)ncb * ba::kDenseWsPerBlock * sizeof(double)));
@@ -1022,7 +1031,8 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   for (void *p : {(void *)dL, (void *)dD, (void *)dx, (void *)dd.xc, (void *)dd.row_ptr,
                   (void *)dd.rows, (void *)dd.item_t, (void *)dd.item_I, (void *)dd.tgt_I,
                   (void *)dd.tgt_J, (void *)dd.tgt_src_ptr, (void *)dd.src_t, (void *)dd.col_x,
-                  (void *)dd.tgt_desc, (void *)dd.back_desc})
+                  (void *)dd.tgt_desc, (void *)dd.back_desc, (void *)dd.f_desc,
+                  (void *)dd.f_pend, (void *)dd.cbuf})
     (void)hipFree(p);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -15,6 +15,7 @@
 #include "ba_device.h"
 #include "ba_dense_sched.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace ba {
@@ -114,46 +115,14 @@ __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
   }
 }
 
-#ifdef BA_DENSE_DBG
-__device__ long long g_dense_dbg[64];
-#define DD_STAMP() { if (threadIdx.x == 0 && blockIdx.x == 0 && t0 == 0 && dd_n < 64) g_dense_dbg[dd_n++] = clock64(); }
-#else
-#define DD_STAMP()
-#endif
-__global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
-                                                   int t0, double *ws_all,
-                                                   const int *done) {
-#ifdef BA_DENSE_DBG
-  int dd_n = 0;
-#endif
-  DD_STAMP()
-  // one workgroup per diagonal tile of the level (independent tiles)
-  const int k0 = (t0 + blockIdx.x) * NB;
-  double *ws = ws_all + (size_t)(t0 + blockIdx.x) * kDenseWsPerBlock;
-  constexpr int LS = NB + 1;
-  constexpr int ES = 17;
-  __shared__ double Lb[NB * LS];      // Lb[c*LS + r]
-  __shared__ double Eb[NP][16 * ES];  // Eb[p][k*ES + c] = E_pp[k][c]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// Cholesky of the NB x NB tile held in LDS (Lb[c*LS + r], lower triangle) by
+// left-looking 16-column panels; leaves L in Lb and the tile inverses
+// E_pp = L_pp^-T in Eb.  All 256 threads of the workgroup call it.
+constexpr int LS = NB + 1;
+constexpr int ES = 17;
+__device__ __forceinline__ void factor_tile_lds(double *Lb, double (*Eb)[16 * ES], int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  // the block is requested before the `done` word is examined: one memory
-  // latency for both instead of two in a row
-  double lv[NB * NB / 256];
-#pragma unroll
-  for (int k = 0; k < NB * NB / 256; ++k) {
-    const int e = tid + 256 * k;
-    const int c = e / NB, r = e % NB;
-    lv[k] = (r >= c) ? L[(size_t)(k0 + c) * ld + k0 + r] : 0.0;
-  }
-  if (done && *done) return;
-#pragma unroll
-  for (int k = 0; k < NB * NB / 256; ++k) {
-    const int e = tid + 256 * k;
-    Lb[(e / NB) * LS + e % NB] = lv[k];
-  }
-  for (int e = tid; e < NP * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
-  __syncthreads();
-  DD_STAMP()
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     // (1) left-looking update of panel p: tile (ti,p) -= sum_kt L(ti,kt) L(p,kt)^T
@@ -175,7 +144,6 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
       }
       __syncthreads();
     }
-    DD_STAMP()
     // (2) factor the diagonal tile (wave 0)
     if (wv == 0) {
       const int r = lr, q = lk;
@@ -194,7 +162,6 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
         if (r == c) Eb[p][r * ES + c] = (g[j] > 0.0) ? 1.0 / g[j] : 0.0;
       }
     }
-    DD_STAMP()
     __syncthreads();
     // (3) TRSM of the tiles below: X = T * E_pp   (waves 1..3)
     if (p < NP - 1) {
@@ -215,6 +182,46 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
       __syncthreads();
     }
   }
+}
+
+#ifdef BA_DENSE_DBG
+__device__ long long g_dense_dbg[64];
+#define DD_STAMP() { if (threadIdx.x == 0 && blockIdx.x == 0 && t0 == 0 && dd_n < 64) g_dense_dbg[dd_n++] = clock64(); }
+#else
+#define DD_STAMP()
+#endif
+__global__ __launch_bounds__(256) void k_chol_diag(const double *L, int ld,
+                                                   int t0, double *ws_all,
+                                                   const int *done) {
+#ifdef BA_DENSE_DBG
+  int dd_n = 0;
+#endif
+  DD_STAMP()
+  // one workgroup per diagonal tile of the level (independent tiles)
+  const int k0 = (t0 + blockIdx.x) * NB;
+  double *ws = ws_all + (size_t)(t0 + blockIdx.x) * kDenseWsPerBlock;
+  __shared__ double Lb[NB * LS];      // Lb[c*LS + r]
+  __shared__ double Eb[NP][16 * ES];  // Eb[p][k*ES + c] = E_pp[k][c]
+  const int tid = threadIdx.x;
+  // the block is requested before the `done` word is examined: one memory
+  // latency for both instead of two in a row
+  double lv[NB * NB / 256];
+#pragma unroll
+  for (int k = 0; k < NB * NB / 256; ++k) {
+    const int e = tid + 256 * k;
+    const int c = e / NB, r = e % NB;
+    lv[k] = (r >= c) ? L[(size_t)(k0 + c) * ld + k0 + r] : 0.0;
+  }
+  if (done && *done) return;
+#pragma unroll
+  for (int k = 0; k < NB * NB / 256; ++k) {
+    const int e = tid + 256 * k;
+    Lb[(e / NB) * LS + e % NB] = lv[k];
+  }
+  for (int e = tid; e < NP * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
+  __syncthreads();
+  DD_STAMP()
+  factor_tile_lds(Lb, Eb, tid);
   DD_STAMP()
   for (int e = tid; e < NB * NB; e += 256) {
     const int c = e / NB, r = e % NB;
@@ -375,6 +382,210 @@ __global__ __launch_bounds__(256) void k_chol_update(double *L, int ld, int tg0,
       }
 }
 
+// ---- fused level: diagonal factorisation + TRSM + outer products ----------
+// One workgroup per SOURCE tile p of the level, one launch per level (instead
+// of diag / TRSM / update launches, each a dependent round trip):
+//   1. A_pp = base tile - its pending contribution tiles;  L_pp, E = chol(A_pp)
+//   2. every row tile I of p:  P_I = (A_Ip - pending) L_pp^-T  -> L (for the
+//      backward sweep) and LDS
+//   3. every pair (a >= c) of row tiles:  contribution tile  P_a P_c^T  -> cbuf
+// Nothing is updated in place, so no workgroup ever waits for another one of
+// the same launch; the sums are formed by the (single) consumer of each tile
+// in ascending contribution id: deterministic.
+constexpr int PS = NB + 1;
+constexpr int MT2 = NB / 16;
+constexpr int RG = 4 / NP;        // row tiles handled at once by the four waves
+constexpr int TE = NB * NB / 256; // tile elements per thread
+constexpr int PCH = 8;            // pending contributions fetched per batch
+__global__ __launch_bounds__(256) void k_chol_level(double *L, int ld, int npad, int t0,
+                                                    const int *__restrict__ f_desc,
+                                                    const int *__restrict__ rows,
+                                                    const int *__restrict__ f_pend,
+                                                    double *cbuf, double *ws_all,
+                                                    const int *done) {
+  __shared__ double Lb[NB * LS];
+  __shared__ double Eb[NP][16 * ES];
+  __shared__ double Pb[kMaxFusedRows][NB * PS];  // Pb[a][k*PS + row]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+#ifdef BA_DENSE_DBG
+  int dd_n = 0;
+#endif
+  DD_STAMP()
+  const int p = t0 + blockIdx.x;
+  const int k0 = p * NB;
+  const int4 *dq = (const int4 *)(f_desc + 16 * (size_t)p);
+  const int4 d0 = dq[0];  // nrow, row_begin, pend_begin, pend_n
+  const int4 d1 = dq[1];  // out_base, npairs
+  const int4 d2 = dq[2], d3 = dq[3];  // first eight row tiles
+  const int dn = done ? *done : 0;
+  const int nrow = d0.x;
+  if (dn) return;
+  // ---- 1. every tile of this column, requested at once: base values ----
+  // (dependent-load chain of the whole kernel: record -> bases + pending list
+  //  -> contribution tiles)
+  double lv[TE];
+#pragma unroll
+  for (int k = 0; k < TE; ++k) {
+    const int e = tid + 256 * k;
+    lv[k] = L[(size_t)(k0 + e / NB) * ld + k0 + e % NB];
+  }
+  for (int a0 = 0; a0 < nrow; a0 += 4) {  // four row tiles in flight
+    double rv[4][TE];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int a = a0 + j;
+      const int I = a >= nrow ? -1
+                  : a == 0 ? d2.x : a == 1 ? d2.y : a == 2 ? d2.z : a == 3 ? d2.w
+                  : a == 4 ? d3.x : a == 5 ? d3.y : a == 6 ? d3.z : a == 7 ? d3.w
+                  : rows[d0.y + a];
+#pragma unroll
+      for (int k = 0; k < TE; ++k) {
+        const int e = tid + 256 * k;
+        const int r = I * NB + e % NB;
+        rv[j][k] = (I >= 0 && r < npad + 16) ? L[(size_t)(k0 + e / NB) * ld + r] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int a = a0 + j;
+      if (a < nrow) {
+#pragma unroll
+        for (int k = 0; k < TE; ++k) {
+          const int e = tid + 256 * k;
+          Pb[a][(e / NB) * PS + e % NB] = rv[j][k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TE; ++k) {
+    const int e = tid + 256 * k;
+    Lb[(e / NB) * LS + e % NB] = lv[k];
+  }
+  for (int e = tid; e < NP * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
+  DD_STAMP()
+  // ---- pending contributions, PCH tiles in flight, subtracted in list order ----
+  // (each thread owns the same tile elements for every tile: no barrier needed)
+  for (int q0 = 0; q0 < d0.w; q0 += PCH) {
+    double cv[PCH][TE];
+    int slot[PCH];
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int q = q0 + j < d0.w ? q0 + j : d0.w - 1;
+      const int2 pe = ((const int2 *)f_pend)[d0.z + q];
+      slot[j] = q0 + j < d0.w ? pe.x : -2;
+      const double *C = cbuf + (size_t)pe.y * NB * NB;
+#pragma unroll
+      for (int k = 0; k < TE; ++k) cv[j][k] = C[tid + 256 * k];
+    }
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      if (slot[j] == -2) continue;
+      double *dst = slot[j] < 0 ? Lb : Pb[slot[j]];
+      const int st = slot[j] < 0 ? LS : PS;
+#pragma unroll
+      for (int k = 0; k < TE; ++k) {
+        const int e = tid + 256 * k;
+        dst[(e / NB) * st + e % NB] -= cv[j][k];
+      }
+    }
+  }
+  __syncthreads();
+  DD_STAMP()
+  // ---- 2. factor the diagonal tile ----
+  factor_tile_lds(Lb, Eb, tid);
+  DD_STAMP()
+  {
+    double *ws = ws_all + (size_t)p * kDenseWsPerBlock;
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int c = e / NB, r = e % NB;
+      ws[e] = (r >= c) ? Lb[c * LS + r] : 0.0;
+    }
+    for (int e = tid; e < NP * 256; e += 256) {
+      const int pp = e >> 8, k = (e >> 4) & 15, c = e & 15;
+      ws[NB * NB + e] = Eb[pp][k * ES + c];
+    }
+  }
+  DD_STAMP()
+  // ---- 3. TRSM of the row tiles, in place in LDS (wave group wv / NP: tile,
+  //         wave wv % NP: 16 of its rows) ----
+  for (int a0 = 0; a0 < nrow; a0 += RG) {
+    const int a = a0 + wv / NP, w = wv % NP;
+    if (a < nrow) {
+      const int I = a == 0 ? d2.x : a == 1 ? d2.y : a == 2 ? d2.z : a == 3 ? d2.w
+                  : a == 4 ? d3.x : a == 5 ? d3.y : a == 6 ? d3.z : a == 7 ? d3.w
+                  : rows[d0.y + a];
+      const int r0 = I * NB + 16 * w;
+      v4f64 A0[NP];
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) A0[pp][g] = Pb[a][(16 * pp + lk + 4 * g) * PS + 16 * w + lr];
+      v4f64 X[NP];
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        v4f64 acc = A0[pp];
+#pragma unroll
+        for (int kq = 0; kq < pp; ++kq)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const double lo = -Lb[(16 * kq + lk + 4 * g) * LS + 16 * pp + lr];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, X[kq][g], acc, 0, 0, 0);
+          }
+        v4f64 out = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const double eo = Eb[pp][(lk + 4 * g) * ES + lr];
+          out = __builtin_amdgcn_mfma_f64_16x16x4f64(eo, acc[g], out, 0, 0, 0);
+        }
+        X[pp] = out;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (r0 < npad + 16) L[(size_t)(k0 + 16 * pp + lk + 4 * g) * ld + r0 + lr] = out[g];
+          Pb[a][(16 * pp + lk + 4 * g) * PS + 16 * w + lr] = out[g];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  DD_STAMP()
+  // ---- 4. contribution tiles, one wave per pair (a >= c), rows[c] a real tile ----
+  for (int k = wv; k < d1.y; k += 4) {
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= k) ++a;
+    const int c = k - a * (a + 1) / 2;
+    v4f64 acc[MT2][MT2];
+#pragma unroll
+    for (int m = 0; m < MT2; ++m)
+#pragma unroll
+      for (int n = 0; n < MT2; ++n) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      double av[MT2], bv[MT2];
+#pragma unroll
+      for (int m = 0; m < MT2; ++m) {
+        av[m] = Pb[c][(kk * 4 + lk) * PS + 16 * m + lr];
+        bv[m] = Pb[a][(kk * 4 + lk) * PS + 16 * m + lr];
+      }
+#pragma unroll
+      for (int m = 0; m < MT2; ++m)
+#pragma unroll
+        for (int n = 0; n < MT2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
+    }
+    double *C = cbuf + (size_t)(d1.x + k) * NB * NB;
+#pragma unroll
+    for (int m = 0; m < MT2; ++m)
+#pragma unroll
+      for (int n = 0; n < MT2; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          C[(16 * m + lk + 4 * g) * NB + 16 * n + lr] = acc[m][n][g];
+  }
+  DD_STAMP()
+}
+
 // ---- backward sweep L^T x = z, one launch per level (reverse order) --------
 // Left-looking: the workgroup of tile t gathers  w = z_t - sum_I L(I,t)^T x_I
 // over the non-zero row tiles I below t (all solved in earlier launches), then
@@ -495,8 +706,19 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const int *done, const DenseSchedule &sc,
                         const DenseDev &dd, hipStream_t s) {
   const int row_limit = npad + 16;  // rows that carry data (rhs = row npad)
+  // The fused one-launch-per-level path is opt-in (BA_DENSE_FUSED=1): on C4 it
+  // measured no faster than the three-kernel path (886 vs 876 us per LM
+  // iteration) because tiles that survive many levels collect long pending
+  // lists, which their single consumer then gathers serially.
+  const char *fz = getenv("BA_DENSE_FUSED");
+  const bool fused = sc.fused_ok && dd.f_desc && fz && fz[0] == '1';
   for (int l = 0; l < sc.nlev; ++l) {
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;
+    if (fused) {
+      BA_LAUNCH(K_CHOL_LEVEL, k_chol_level, dim3(nt), dim3(256), s, L, ld, npad, t0,
+                dd.f_desc, dd.rows, dd.f_pend, dd.cbuf, Ldiag, done);
+      continue;
+    }
     BA_LAUNCH(K_CHOL_DIAG, k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag,
                        done);
     const int it0 = sc.item_ptr[l], ni = sc.item_ptr[l + 1] - it0;

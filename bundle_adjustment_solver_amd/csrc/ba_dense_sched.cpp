@@ -1,6 +1,8 @@
 // ba_dense_sched.cpp — see ba_dense_sched.h.  Host-only.
 #include "ba_dense_sched.h"
 
+#include <map>
+
 #include <algorithm>
 #include <tuple>
 
@@ -142,6 +144,55 @@ void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj_in,
     q[2] = s.tgt_src_ptr[tg + 1] - s.tgt_src_ptr[tg];
     q[3] = s.tgt_src_ptr[tg];
     for (int k = 0; k < 4 && k < q[2]; ++k) q[4 + k] = s.src_t[q[3] + k];
+  }
+  // ---- fused schedule with lazily applied contributions ----
+  {
+    s.fused_ok = true;
+    long long total = 0;
+    for (int p = 0; p < n; ++p) {
+      const long long nrow = s.row_ptr[p + 1] - s.row_ptr[p];
+      if (nrow > kMaxFusedRows) s.fused_ok = false;
+      total += nrow * (nrow + 1) / 2 - 1;
+    }
+    if (total > kMaxContrib) s.fused_ok = false;
+    if (s.fused_ok) {
+      std::map<std::pair<int, int>, std::vector<int>> pending;
+      s.f_desc.assign(16 * (size_t)n, -1);
+      s.f_pend.clear();
+      int next = 0;
+      for (int p = 0; p < n; ++p) {  // positions are in elimination order
+        int *q = &s.f_desc[16 * (size_t)p];
+        const int b = s.row_ptr[p], e = s.row_ptr[p + 1];
+        q[0] = e - b;
+        q[1] = b;
+        q[2] = (int)s.f_pend.size() / 2;
+        auto take = [&](int I, int slot) {
+          auto it = pending.find({I, p});
+          if (it == pending.end()) return;
+          for (int cid : it->second) {
+            s.f_pend.push_back(slot);
+            s.f_pend.push_back(cid);
+          }
+          pending.erase(it);
+        };
+        take(p, -1);
+        for (int a = b; a < e; ++a) take(s.rows[a], a - b);
+        q[3] = (int)s.f_pend.size() / 2 - q[2];
+        q[4] = next;
+        int k = 0;
+        for (int a = b; a < e; ++a)
+          for (int c = b; c <= a; ++c)
+            if (s.rows[c] < n) {
+              pending[{s.rows[a], s.rows[c]}].push_back(next + k);
+              ++k;
+            }
+        q[5] = k;
+        q[6] = q[7] = 0;
+        for (int a = 0; a < 8 && b + a < e; ++a) q[8 + a] = s.rows[b + a];
+        next += k;
+      }
+      s.n_contrib = next;
+    }
   }
   s.back_desc.assign(8 * (size_t)n, -1);
   for (int p = 0; p < n; ++p) {

@@ -26,6 +26,8 @@
 
 namespace ba {
 
+constexpr int kMaxFusedRows = 12;     // row tiles per source held in LDS
+constexpr int kMaxContrib = 32768;    // contribution tiles (8 KiB each at order 32)
 constexpr int kPosesPerTile = 5;  // 30 columns + 2 padding columns per tile
 
 struct DenseSchedule {
@@ -44,6 +46,21 @@ struct DenseSchedule {
   //   tgt_desc[8 tg ..] = { I, J, nsrc, src_begin, first four sources (-1 pad) }
   //   back_desc[8 p ..] = { nrow (without the rhs block), row_begin, first six rows }
   std::vector<int> tgt_desc, back_desc;
+  // FUSED level schedule (one launch per level, see k_chol_level): every source
+  // tile writes its outer products P_a P_c^T as separate CONTRIBUTION tiles
+  // instead of updating the targets in place; a tile subtracts its pending
+  // contributions when it is consumed (as a diagonal tile or as a row tile of
+  // the column being eliminated).  Used when every tile has at most
+  // kMaxFusedRows row tiles (incl. the rhs block) and the number of
+  // contribution tiles stays below kMaxContrib (banded / block-sparse systems);
+  // dense patterns keep the in-place three-kernel path.
+  //   f_desc[16 p ..] = { nrow, row_begin, pend_begin, pend_n, out_base, npairs, 0, 0,
+  //                       first eight row tiles (-1 pad) }
+  //   f_pend[2 k ..]  = { row slot a (-1: the diagonal tile), contribution id }:
+  //                     the pending contributions of position p's tiles
+  bool fused_ok = false;
+  int n_contrib = 0;
+  std::vector<int> f_desc, f_pend;
   double fill = 1.0;        // non-zero factor tiles / all lower tiles
   double flops = 0.0;       // executed flops of factor + solves (estimate)
 };

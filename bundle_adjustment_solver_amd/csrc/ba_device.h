@@ -141,7 +141,7 @@ constexpr int kDenseWsPerBlock = kDenseNb * kDenseNb + (kDenseNb / 16) * 256;
 enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
   K_SCHUR_LDS, K_SCHUR_PARTIAL, K_RHS_FINAL, K_SCHUR_FINAL, K_SCATTER,
-  K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_BACKSUB_UPDATE,
+  K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_BACKSUB_UPDATE,
   K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_COUNT
 };
 struct KernelTimer {
@@ -193,6 +193,9 @@ struct DenseDev {
   int *tgt_I = nullptr, *tgt_J = nullptr;        // update targets
   int *tgt_src_ptr = nullptr, *src_t = nullptr;  // their source panels
   int *tgt_desc = nullptr, *back_desc = nullptr; // 8-int inline records
+  // fused level path (DenseSchedule::fused_ok)
+  int *f_desc = nullptr, *f_pend = nullptr;
+  double *cbuf = nullptr;  // n_contrib contribution tiles (NB x NB, column-major)
   int *col_x = nullptr;   // npad: column -> index into x (6*pose + r) or -1
   double *xc = nullptr;   // npad: solution in column order
 };

@@ -271,3 +271,24 @@ def test_reproducible_bits(built):
             assert (outs[0][0] == o[0]).all()
             assert (outs[0][1] == o[1]).all()
             assert outs[0][2] == o[2]
+
+
+def test_fused_level_factorisation_matches_default_path(built):
+    """BA_DENSE_FUSED=1 (one launch per elimination level, contributions applied
+    lazily) must reproduce the default three-kernel factorisation."""
+    import os
+    sc = scenes.synthetic_ba_scene(40, 1500, 5, True, seed=11)
+    pr = scenes.scaled_problem(sc)
+    xs = []
+    for flag in ("0", "1"):
+        os.environ["BA_DENSE_FUSED"] = flag
+        try:
+            p = make_gpu(pr)
+            p.stage_linearize(100.0, 1.0)
+            p.stage_schur()
+            p.stage_solve_reduced()
+            xs.append(p.get_xy()[0].copy())
+        finally:
+            os.environ.pop("BA_DENSE_FUSED", None)
+    assert np.abs(xs[0]).max() > 0
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-9 * np.abs(xs[0]).max()

@@ -23,7 +23,7 @@ print("rc", lib.ba_debug_read_dense(out))
 t = np.array(out[:])
 n = int((t != 0).sum())
 d = np.diff(t[:n])
-names = ["load+sync"] + sum([["p%d upd" % p, "p%d potrf" % p] for p in range(4)], []) + ["last trsm", "store"]
+names = ["desc+bases", "pending", "potrf", "ws store", "trsm", "contrib"]
 print("total cycles", t[n - 1] - t[0])
 for k in range(n - 1):
     print("  %-10s %7d" % (names[k] if k < len(names) else "?", d[k]))
