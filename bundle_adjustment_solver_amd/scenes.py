@@ -251,3 +251,45 @@ def pose_only_scene(n=10_000, seed=SEED_BASE + 5, pixel_sigma=0.0):
         uv = (uv + rng.normal(0, pixel_sigma, uv.shape)).astype(np.float32)
     return dict(X=X, uv=uv, fx=fx, fy=fy, cx=cx, cy=cy, T_true=T_true,
                 T_init=np.eye(4, dtype=np.float32))
+
+
+def hover_scene(n_pose, n_pt, n_cam, seed, n_fixed=2, visible_frac=1.0,
+                pose_noise=0.02, point_noise=0.1):
+    """Test scene with arbitrary camera count and dense visibility: the rig
+    hovers around the origin looking down +z at a cloud of points, every camera
+    of every pose sees every point (or a random `visible_frac` of them).  Used
+    for the structure edge cases the window scenes cannot produce: landmarks
+    seen by more than 128 poses, rigs with more than 8 cameras, ragged
+    landmarks."""
+    rng = np.random.default_rng(seed)
+    intr = np.tile(np.array([[FX, FY, CX, CY]]), (n_cam, 1))
+    T_cj = np.tile(np.eye(4), (n_cam, 1, 1))
+    T_cj[:, 0, 3] = -0.05 * np.arange(n_cam)           # cameras side by side
+    T_wc_true = np.tile(np.eye(4), (n_pose, 1, 1))
+    for k in range(n_pose):
+        ang = rng.uniform(-0.03, 0.03, 3)
+        T_wc_true[k, :3, :3] = _rot("x", ang[0]) @ _rot("y", ang[1]) @ _rot("z", ang[2])
+        T_wc_true[k, :3, 3] = rng.uniform(-0.3, 0.3, 3)
+    X_true = np.stack([rng.uniform(-1.5, 1.5, n_pt), rng.uniform(-1.0, 1.0, n_pt),
+                       rng.uniform(6.0, 10.0, n_pt)], 1)
+    T_cw = _inv(T_wc_true)
+    oc, op, oq, uv = [], [], [], []
+    for j in range(n_pose):
+        for c in range(n_cam):
+            T = T_cj[c] @ T_cw[j]
+            Xl = X_true @ T[:3, :3].T + T[:3, 3]
+            u = intr[c, 0] * Xl[:, 0] / Xl[:, 2] + intr[c, 2]
+            v = intr[c, 1] * Xl[:, 1] / Xl[:, 2] + intr[c, 3]
+            sel = np.nonzero(rng.uniform(size=n_pt) < visible_frac)[0]
+            oc.append(np.full(sel.size, c)); op.append(np.full(sel.size, j))
+            oq.append(sel); uv.append(np.stack([u[sel], v[sel]], 1))
+    T_wc_init = T_wc_true.copy()
+    T_wc_init[n_fixed:, :3, 3] += rng.uniform(-pose_noise, pose_noise,
+                                              (n_pose - n_fixed, 3))
+    return dict(
+        intr=intr, T_cj=T_cj, T_wc_true=T_wc_true, T_wc_init=T_wc_init,
+        X_true=X_true, X_init=X_true + rng.uniform(-point_noise, point_noise, (n_pt, 3)),
+        pose_fixed=np.arange(n_pose) < n_fixed, pt_fixed=np.zeros(n_pt, bool),
+        obs_cam=np.concatenate(oc).astype(np.int32),
+        obs_pose=np.concatenate(op).astype(np.int32),
+        obs_pt=np.concatenate(oq).astype(np.int32), obs_uv=np.concatenate(uv))

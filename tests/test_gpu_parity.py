@@ -292,3 +292,82 @@ def test_fused_level_factorisation_matches_default_path(built):
             os.environ.pop("BA_DENSE_FUSED", None)
     assert np.abs(xs[0]).max() > 0
     assert np.abs(xs[0] - xs[1]).max() <= 1e-9 * np.abs(xs[0]).max()
+
+
+def _compare_solve(pr, iters=6, tol_cost=1e-7, tol_par=1e-6):
+    g, o = make_gpu(pr), O.Oracle(pr)
+    lam = 3.0
+    o.linearize(1.0); o.damp_invert(lam); o.schur()
+    g.stage_linearize(lam, 1.0); g.stage_schur()
+    S, rhs = g.get_S()
+    oS, orhs = o.get_S()
+    assert relerr(S, oS) < 1e-9 and relerr(rhs, orhs) < 1e-9
+    rows, _ = g.solve(O.make_options(max_iter=iters, thr_step=0, thr_cost=0,
+                                     cls=BaOptions))
+    orows, _ = o.solve(O.make_options(max_iter=iters, thr_step=0, thr_cost=0))
+    assert len(rows) == len(orows) == iters
+    for a, b in zip(rows, orows):
+        assert a.iteration_status == b.iteration_status
+        assert relerr(a.trial_cost, b.trial_cost) < tol_cost
+    assert relerr(g.get_poses(), o.get_poses()) < tol_par
+    assert relerr(g.get_points()[0], o.get_points()) < tol_par
+    return g, o
+
+
+def test_landmarks_seen_by_more_than_128_poses(built):
+    """Landmarks with more than kSchurPairs (128) pose pairs leave the LDS
+    super-run path: W goes straight to HBM in k_lin_landmarks and their Schur
+    triples are summed by k_schur_partial."""
+    sc = scenes.hover_scene(150, 12, 1, seed=21)
+    # plus a few ordinary landmarks seen by a handful of poses
+    pr = scenes.scaled_problem(sc)
+    assert np.bincount(pr["obs_pt"]).max() == 150
+    _compare_solve(pr, iters=5)
+
+
+def test_rig_with_more_than_eight_cameras(built):
+    """More cameras than the LDS camera table holds (kCamLds = 8): the kernels
+    switch to their global-memory camera path."""
+    sc = scenes.hover_scene(14, 300, 9, seed=22, visible_frac=0.7)
+    _compare_solve(scenes.scaled_problem(sc), iters=5)
+
+
+def test_ragged_and_duplicate_observations(built):
+    """Landmarks with one observation, several observations of one
+    (camera, pose, landmark) triple, three cameras: the last-writer rule picks
+    the W block, everything else sums."""
+    sc = scenes.hover_scene(20, 200, 3, seed=23, visible_frac=0.15)
+    # duplicate 50 observations (appended: they become the last writers)
+    rng = np.random.default_rng(5)
+    dup = rng.integers(0, sc["obs_pt"].size, 50)
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        sc[k] = np.concatenate([sc[k], sc[k][dup]])
+    # landmarks 0..9 keep a single observation, landmark 10 none at all
+    keep = np.ones(sc["obs_pt"].size, bool)
+    for i in range(10):
+        idx = np.nonzero(sc["obs_pt"] == i)[0]
+        keep[idx[1:]] = False
+    keep[sc["obs_pt"] == 10] = False
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        sc[k] = sc[k][keep]
+    pr = scenes.scaled_problem(sc)
+    cnt = np.bincount(pr["obs_pt"], minlength=200)
+    assert (cnt[:10] == 1).all() and cnt[10] == 0
+    _compare_solve(pr, iters=5, tol_par=1e-5)
+
+
+def test_all_points_fixed_and_single_free_pose(built):
+    """No optimisable landmark (structure-less pose refinement through the
+    full solver) and the smallest reduced system (one free pose)."""
+    sc = scenes.hover_scene(6, 80, 2, seed=24)
+    sc["pt_fixed"][:] = True
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    rows, _ = g.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0, cls=BaOptions))
+    orows, _ = o.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0))
+    for a, b in zip(rows, orows):
+        assert a.iteration_status == b.iteration_status
+        assert relerr(a.trial_cost, b.trial_cost) < 1e-7
+    assert relerr(g.get_poses(), o.get_poses()) < 1e-6
+    sc = scenes.hover_scene(3, 50, 1, seed=25, n_fixed=2)
+    _compare_solve(scenes.scaled_problem(sc), iters=5)
