@@ -164,6 +164,13 @@ extern thread_local KernelTimer *g_ktimer;
     if (::ba::g_ktimer && ::ba::g_ktimer->on) ::ba::g_ktimer->end(stream);  \
   } while (0)
 
+// Pins a wave-uniform 32-bit value: everything it depends on (typically a
+// scalar load) has to be issued AND complete before this point, and the
+// compiler cannot sink those loads below a later branch.  Used to request a
+// workgroup's record together with the control word instead of one after the
+// other (`if (ctrl->done) return;` first costs a full scalar-load latency).
+#define BA_KEEP_S(x) asm volatile("" ::"s"(x))
+
 // ---- launchers (ba_kernels.hip) ----
 // sel: 0 = accepted parameters, 1 = trial parameters
 void launch_cost(const DevProblem &d, int sel, hipStream_t s);

@@ -360,6 +360,11 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
   const int buf = d.ctrl->cur;
   const double huber = d.ctrl->huber;
   const double lp1 = 1.0 + d.ctrl->lambda;
+  BA_KEEP_S((int)lc.pb);
+  BA_KEEP_S((int)lc.ob);
+  BA_KEEP_S(lc.l0);
+  BA_KEEP_S(lc.no);
+  BA_KEEP_S(done);
   if (LDSCAM) stage_cams(d, cams_s);
   const int tid = threadIdx.x;
   const int64_t pb = lc.pb;
@@ -520,6 +525,9 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   const int done = d.ctrl->done;
   const int buf = d.ctrl->cur;
   const double huber = d.ctrl->huber;
+  BA_KEEP_S(__builtin_amdgcn_readfirstlane((int)b));
+  BA_KEEP_S(__builtin_amdgcn_readfirstlane(j));
+  BA_KEEP_S(done);
   __syncthreads();  // cams_s
   if (done || !live || b >= e) {
     if (!done && live) {  // empty chunk: zero partial sums
@@ -663,7 +671,6 @@ __device__ long long g_schur_dbg[4][160];
 #define DBG_STAMP()
 #endif
 __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
-  if (d.ctrl->done) return;
 #ifdef BA_SCHUR_DBG
   __shared__ long long dbg_s[160];
   const int dbg_slot = blockIdx.x == 10 ? 0 : blockIdx.x == 700 ? 1 : blockIdx.x == 1200 ? 2 : blockIdx.x == 1900 ? 3 : -1;
@@ -682,6 +689,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   const int tid = threadIdx.x;
   const DevProblem::SupDesc sd = d.sup_desc[blockIdx.x];
   const int ns = sd.ns;
+  const int done = d.ctrl->done;
+  BA_KEEP_S(sd.chunk_begin);
+  BA_KEEP_S(done);
+  if (done) return;
   // slots are dealt to the four waves (at most spw per wave, never straddling one);
   // every slot gets tps = 64 / spw lanes (at most 32, any value: the final
   // reduction is a guarded shuffle-down tree)
@@ -985,6 +996,10 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
   const DevProblem::LmChunk lc = d.lm_chunk[blockIdx.x];
   const int done = d.ctrl->done;
   const int cur = d.ctrl->cur;
+  BA_KEEP_S((int)lc.pb);
+  BA_KEEP_S(lc.l0);
+  BA_KEEP_S(lc.np);
+  BA_KEEP_S(done);
   if (done) return;
   const int tid = threadIdx.x;
   const double *__restrict__ Xc = d.pts[cur];
