@@ -149,7 +149,8 @@ int enqueue_iteration(ba_handle *h) {
   const bool ov = h->overlap && !h->timing;
   mark(h, 0);
   if (ov) {
-    ba::launch_linearize_schur_overlapped(d, s, h->side_stream, h->ev_fork, h->ev_join);
+    ba::launch_linearize_schur_overlapped(d, s, h->side_stream, h->ev_fork, h->ev_join,
+                                          /*direct=*/!h->ar_fn);
     mark(h, 1);
   } else {
     ba::launch_linearize(d, s);
@@ -159,7 +160,7 @@ int enqueue_iteration(ba_handle *h) {
   mark(h, 2);
   if (xchg(h, 0)) return -1;
   mark(h, 3);
-  ba::launch_scatter(d, s);
+  if (!(ov && !h->ar_fn)) ba::launch_scatter(d, s);  // else placed by k_schur_final_direct
   ba::launch_dense_solve(d, h->sched, h->ddev, s);
   mark(h, 4);
   if (ov)
@@ -168,11 +169,17 @@ int enqueue_iteration(ba_handle *h) {
     ba::launch_backsub_update(d, s);
   mark(h, 5);
   ba::launch_cost(d, 1, s);
-  ba::launch_scalars(d, s);
-  mark(h, 6);
-  if (xchg(h, 1)) return -1;
-  mark(h, 7);
-  ba::launch_control(d, s);
+  if (h->ar_fn) {
+    ba::launch_scalars(d, s);
+    mark(h, 6);
+    if (xchg(h, 1)) return -1;
+    mark(h, 7);
+    ba::launch_control(d, s);
+  } else {  // nothing to exchange: the reduction workgroup also takes the LM decision
+    ba::launch_scalars_and_control(d, s);
+    mark(h, 6);
+    mark(h, 7);
+  }
   mark(h, 8);
   ba::g_ktimer = nullptr;
   if (h->timing) {

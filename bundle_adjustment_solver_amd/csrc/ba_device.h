@@ -177,15 +177,17 @@ void launch_cost(const DevProblem &d, int sel, hipStream_t s);
 void launch_linearize(const DevProblem &d, hipStream_t s);
 void launch_schur(const DevProblem &d, hipStream_t s);
 // two-stream forms of linearize+schur and backsub+update (see ba_kernels.hip)
+// direct: single GPU, S and rhs are also placed in the dense matrix (no k_scatter)
 void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
                                        hipStream_t s2, hipEvent_t fork,
-                                       hipEvent_t join);
+                                       hipEvent_t join, bool direct);
 void launch_backsub_update_overlapped(const DevProblem &d, hipStream_t s,
                                       hipStream_t s2, hipEvent_t fork,
                                       hipEvent_t join);
 void launch_backsub_update(const DevProblem &d, hipStream_t s);
 void launch_scatter(const DevProblem &d, hipStream_t s);
 void launch_scalars(const DevProblem &d, hipStream_t s);
+void launch_scalars_and_control(const DevProblem &d, hipStream_t s);  // single GPU
 void launch_control(const DevProblem &d, hipStream_t s);
 void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s);
 

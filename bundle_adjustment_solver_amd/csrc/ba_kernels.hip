@@ -601,9 +601,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
 // buffer behind the S blocks.  BCinv_b_j = sum_i V_ji b_i is accumulated next to the diagonal
 // block (j,j) by the Schur kernels (entries 36..41 of every slot partial).
 // One thread per (pose, component); runs after the Schur kernels.
-__global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
-  if (d.ctrl->done) return;
-  const int t = blockIdx.x * kBlock + threadIdx.x;
+template <bool DIRECT>
+__device__ __forceinline__ void rhs_final_body(const DevProblem &d, int t) {
   if (t >= d.N * 6) return;
   const int j = t / 6, r = t % 6;
   const int64_t blk = d.diag_blk[j];
@@ -612,7 +611,14 @@ __global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
     bc += d.spart2[(size_t)d.contrib_slot[q] * kSlotStride + 36 + r];
   for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
     bc += d.spart[(size_t)ch * kSlotStride + 36 + r];
-  d.Spk[(size_t)d.B * 36 + t] = d.a[(size_t)j * 6 + r] - bc;
+  const double val = d.a[(size_t)j * 6 + r] - bc;
+  d.Spk[(size_t)d.B * 36 + t] = val;
+  if (DIRECT)  // rhs rides as row `npad` of the dense matrix (see k_scatter)
+    d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = val;
+}
+__global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
+  if (d.ctrl->done) return;
+  rhs_final_body<false>(d, blockIdx.x * kBlock + threadIdx.x);
 }
 
 // Landmark-major Schur complement (reference :859-872).  One workgroup per
@@ -908,10 +914,9 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
 // :878-888).  One workgroup per block: 7 parts x 36
 // entries; part q sums every 7th slot partial of the block, the parts are then
 // added in order 0..6 (fixed tree: deterministic).
-__global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
-  if (d.ctrl->done) return;
-  __shared__ double part[7][36];
-  const int64_t blk = blockIdx.x;
+template <bool DIRECT>
+__device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t blk,
+                                                 double (*part)[36]) {
   const int q = threadIdx.x / 36, e = threadIdx.x - q * 36;
   if (q < 7) {
     double s = 0.0;
@@ -929,7 +934,34 @@ __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
 #pragma unroll
   for (int k = 1; k < 7; ++k) s += part[k][e];
   const int j = d.sblk_j[blk], k = d.sblk_k[blk];
-  d.Spk[(size_t)blk * 36 + e] = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
+  const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
+  d.Spk[(size_t)blk * 36 + e] = val;
+  if (DIRECT) {  // same placement as k_scatter
+    const int r = e / 6, c = e % 6;
+    int row = d.pose_col[k] + c, col = d.pose_col[j] + r;
+    if (j == k && row < col) return;
+    if (row < col) {
+      const int t2 = row;
+      row = col;
+      col = t2;
+    }
+    d.L[(size_t)col * d.ld + row] = val;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ double part[7][36];
+  schur_final_body<false>(d, blockIdx.x, part);
+}
+// Single GPU: blocks of S, rhs and their placement in the dense matrix in one
+// launch (the packed buffer is still written: the readers use it).
+__global__ __launch_bounds__(kBlock) void k_schur_final_direct(DevProblem d) {
+  if (d.ctrl->done) return;
+  __shared__ double part[7][36];
+  if ((int64_t)blockIdx.x < d.B)
+    schur_final_body<true>(d, blockIdx.x, part);
+  else
+    rhs_final_body<true>(d, (int)(blockIdx.x - d.B) * kBlock + threadIdx.x);
 }
 
 // Packed S blocks and rhs -> dense column-major lower matrix (reference
@@ -1200,19 +1232,32 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
 // Reduce the block partials into the exchange scalars.
 //   mode 0: scal[0] = cost only (initial cost)
 //   mode 1: scal[0] = trial cost, scal[1] = model estimate, scal[2] = sum|y|
-__global__ __launch_bounds__(kBlock) void k_scalars(DevProblem d, int mode) {
+__device__ void control_step(const DevProblem &d);
+
+// mode 0: cost only; 1: all LM scalars; 2: all LM scalars, then the trust-region
+// control step by the same workgroup (single GPU: nothing to all-reduce in between)
+constexpr int kScalBlock = 1024;
+__global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode) {
   if (d.ctrl->done) return;
-  __shared__ double sm[4];
+  __shared__ double sm[kScalBlock / 64];
   double c = 0.0, e = 0.0, n = 0.0, pe = 0.0, pn = 0.0;
-#pragma unroll 4
-  for (int k = threadIdx.x; k < kCostGrid; k += kBlock) c += d.cost_part[k];
-  if (mode == 1) {
+#pragma unroll 1
+  for (int k = threadIdx.x; k < kCostGrid; k += kScalBlock) c += d.cost_part[k];
+  if (mode >= 1) {
     const double2 *lp = (const double2 *)d.lm_part;
-#pragma unroll 8
-    for (int k = threadIdx.x; k < d.n_bchunk; k += kBlock) {
-      const double2 v = lp[k];
-      e += v.x;
-      n += v.y;
+    // eight independent loads in flight per thread
+    for (int k0 = threadIdx.x; k0 < d.n_bchunk; k0 += 8 * kScalBlock) {
+      double2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * kScalBlock;
+        v[u] = k < d.n_bchunk ? lp[k] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        e += v[u].x;
+        n += v[u].y;
+      }
     }
     if (threadIdx.x < kPoseGrid) {
       pe = d.pose_part[2 + 2 * threadIdx.x + 0];
@@ -1225,14 +1270,18 @@ __global__ __launch_bounds__(kBlock) void k_scalars(DevProblem d, int mode) {
   const double tpe = block_sum(pe, sm);
   const double tpn = block_sum(pn, sm);
   if (threadIdx.x == 0) {
-    if (mode == 1) {
+    if (mode >= 1) {
       d.pose_part[0] = tpe;
       d.pose_part[1] = tpn;
     }
     d.scal[0] = tc;
-    d.scal[1] = (mode == 1) ? te + tpe : 0.0;
-    d.scal[2] = (mode == 1) ? tn : 0.0;
+    d.scal[1] = (mode >= 1) ? te + tpe : 0.0;
+    d.scal[2] = (mode >= 1) ? tn : 0.0;
     d.scal[3] = 0.0;
+    if (mode == 2) {
+      __threadfence();
+      control_step(d);
+    }
   }
 }
 
@@ -1242,9 +1291,8 @@ __global__ void k_init_ctrl_cost(DevProblem d) {
   d.ctrl->t_last = wall_clock64();
 }
 
-// Trust region, convergence and iteration log (reference :928-1007).
-__global__ void k_control(DevProblem d) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Trust region, convergence and iteration log (reference :928-1007); one thread.
+__device__ void control_step(const DevProblem &d) {
   DevCtrl *c = d.ctrl;
   if (c->done) return;
   const double current_cost = d.scal[0];
@@ -1301,6 +1349,11 @@ __global__ void k_control(DevProblem d) {
   if (conv || c->iter >= c->max_iter) c->done = 1;
 }
 
+__global__ void k_control(DevProblem d) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  control_step(d);
+}
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
@@ -1355,7 +1408,7 @@ void launch_schur(const DevProblem &d, hipStream_t s) {
 // so they run beside k_lin_landmarks and k_schur_lds instead of after them.
 void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
                                        hipStream_t s2, hipEvent_t fork,
-                                       hipEvent_t join) {
+                                       hipEvent_t join, bool direct) {
   (void)hipEventRecord(fork, s);
   (void)hipStreamWaitEvent(s2, fork, 0);
   launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, &d.ctrl->done, s2);
@@ -1379,6 +1432,11 @@ void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
   if (d.n_tchunk > 0)
     hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
   (void)hipStreamWaitEvent(s, join, 0);
+  if (direct) {
+    hipLaunchKernelGGL(k_schur_final_direct,
+                       dim3((unsigned)(d.B + cdiv((int64_t)d.N * 6, kBlock))), dim3(kBlock), 0, s, d);
+    return;
+  }
   if (d.N > 0)
     hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)), dim3(kBlock), 0, s, d);
   if (d.B > 0) hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s, d);
@@ -1410,7 +1468,11 @@ void launch_backsub_update(const DevProblem &d, hipStream_t s) {
 }
 
 void launch_scalars(const DevProblem &d, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kBlock), s, d, 1);
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 1);
+}
+
+void launch_scalars_and_control(const DevProblem &d, hipStream_t s) {
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 2);
 }
 
 void launch_control(const DevProblem &d, hipStream_t s) {
@@ -1423,7 +1485,7 @@ void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s) {
 
 // exposed for ba_api: initial-cost scalar reduction (mode 0)
 void launch_scalars_cost_only(const DevProblem &d, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kBlock), s, d, 0);
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 0);
 }
 
 }  // namespace ba
