@@ -939,7 +939,7 @@ int ba_kernel_count(void) { return ba::K_COUNT; }
 const char *ba_kernel_name(int id) {
   static const char *names[ba::K_COUNT] = {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
-      "k_schur_lds", "k_schur_partial", "k_rhs_final", "k_schur_final", "k_scatter",
+      "k_schur_lds", "k_schur_partial", "k_schur_final", "k_scatter",
       "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_backsub_update",
       "k_pose_update", "k_scalars", "k_control"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";

@@ -140,7 +140,7 @@ constexpr int kDenseWsPerBlock = kDenseNb * kDenseNb + (kDenseNb / 16) * 256;
 // launch duration of each kernel live, on the stream the kernels run on.
 enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
-  K_SCHUR_LDS, K_SCHUR_PARTIAL, K_RHS_FINAL, K_SCHUR_FINAL, K_SCATTER,
+  K_SCHUR_LDS, K_SCHUR_PARTIAL, K_SCHUR_FINAL, K_SCATTER,
   K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_BACKSUB_UPDATE,
   K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_COUNT
 };

@@ -601,26 +601,6 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
 // buffer behind the S blocks.  BCinv_b_j = sum_i V_ji b_i is accumulated next to the diagonal
 // block (j,j) by the Schur kernels (entries 36..41 of every slot partial).
 // One thread per (pose, component); runs after the Schur kernels.
-template <bool DIRECT>
-__device__ __forceinline__ void rhs_final_body(const DevProblem &d, int t) {
-  if (t >= d.N * 6) return;
-  const int j = t / 6, r = t % 6;
-  const int64_t blk = d.diag_blk[j];
-  double bc = 0.0;
-  for (int64_t q = d.blk_contrib_ptr[blk]; q < d.blk_contrib_ptr[blk + 1]; ++q)
-    bc += d.spart2[(size_t)d.contrib_slot[q] * kSlotStride + 36 + r];
-  for (int ch = d.sblk_tchunk_ptr[blk]; ch < d.sblk_tchunk_ptr[blk + 1]; ++ch)
-    bc += d.spart[(size_t)ch * kSlotStride + 36 + r];
-  const double val = d.a[(size_t)j * 6 + r] - bc;
-  d.Spk[(size_t)d.B * 36 + t] = val;
-  if (DIRECT)  // rhs rides as row `npad` of the dense matrix (see k_scatter)
-    d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = val;
-}
-__global__ __launch_bounds__(kBlock) void k_rhs_final(DevProblem d) {
-  if (d.ctrl->done) return;
-  rhs_final_body<false>(d, blockIdx.x * kBlock + threadIdx.x);
-}
-
 // Landmark-major Schur complement (reference :859-872).  One workgroup per
 // SUPER-RUN: a maximal run of consecutive landmarks (locality order) touching
 // at most kSchurSlots distinct blocks of S.  Every block (slot) of the run is
@@ -676,7 +656,7 @@ __device__ long long g_schur_dbg[4][160];
 #else
 #define DBG_STAMP()
 #endif
-__global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
+__global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
 #ifdef BA_SCHUR_DBG
   __shared__ long long dbg_s[160];
   const int dbg_slot = blockIdx.x == 10 ? 0 : blockIdx.x == 700 ? 1 : blockIdx.x == 1200 ? 2 : blockIdx.x == 1900 ? 3 : -1;
@@ -691,7 +671,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   __shared__ uint32_t Ts[kSchurTri];
   __shared__ uint16_t Sp[kSchurSlots + 1];
   __shared__ uint16_t Pl[kSchurPairs];
-  __shared__ DevProblem::ChunkDesc Cdsc[kSchurSuperLandmarks];
+  __shared__ DevProblem::ChunkDesc Cdsc[kSchurSuperChunks];
   const int tid = threadIdx.x;
   const DevProblem::SupDesc sd = d.sup_desc[blockIdx.x];
   const int ns = sd.ns;
@@ -699,22 +679,26 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
   BA_KEEP_S(sd.chunk_begin);
   BA_KEEP_S(done);
   if (done) return;
-  // slots are dealt to the four waves (at most spw per wave, never straddling one);
-  // every slot gets tps = 64 / spw lanes (at most 32, any value: the final
-  // reduction is a guarded shuffle-down tree)
+  // slots are dealt to the four waves (at most spw per wave, never straddling
+  // one); every slot gets tps = 64 / spw lanes (even, at most 32).  A lane owns
+  // HALF a slot: rows 3h..3h+2 of the 6x6 block (18 accumulators + 3 of the
+  // rhs), so that the kernel fits three workgroups per CU; the tps/2 lanes of
+  // one half share the slot's triples and are summed at the end by a guarded
+  // shuffle-down tree.
   const int spw = (ns + 3) >> 2;
-  const int tps = spw <= 2 ? 32 : 64 / spw;
+  const int tps = spw <= 2 ? 32 : ((64 / spw) & ~1);
   const int lane = tid & 63;
   const int sl = lane / tps, sub = lane - sl * tps;
+  const int h = sub & 1, sub2 = sub >> 1, tps2 = tps >> 1;
   // slot ids follow the block order, i.e. the position along the run: dealing
   // them round-robin keeps all four waves busy in every chunk
   const int slot = sl * 4 + (tid >> 6);
   const bool owner = sl < spw && slot < ns;
-  double acc[36], racc[6];
+  double acc[18], racc[3];
 #pragma unroll
-  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (int k = 0; k < 18; ++k) acc[k] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) racc[k] = 0.0;
+  for (int k = 0; k < 3; ++k) racc[k] = 0.0;
   // The run's chunk descriptors are staged in LDS once (vector loads): a scalar
   // load inside the loop would share lgkmcnt with the LDS traffic and expose a
   // full memory latency at the first LDS wait of every chunk.
@@ -800,9 +784,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
     DBG_STAMP()
     if (owner) {
       const int t1 = (int)Sp[slot + 1];
-      for (int t = (int)Sp[slot] + sub; t < t1; t += tps) {
+      for (int t = (int)Sp[slot] + sub2; t < t1; t += tps2) {
         const uint32_t pq = Ts[t];
-        const double *vp = Vs + (pq >> 16) * 18;
+        const double *vp = Vs + (pq >> 16) * 18 + h * 9;  // rows 3h..3h+2 of V
         const double2 *wp = (const double2 *)(Ws + (pq & 0xffffu) * 18);
         // diagonal triple (p == q): also B Cinv b of this pair (reference :864)
         const bool dg = (pq >> 16) == (pq & 0xffffu);
@@ -817,7 +801,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
           w[2 * k + 1] = b2.y;
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
+        for (int r = 0; r < 3; ++r) {
           const double v0 = vp[r * 3 + 0], v1 = vp[r * 3 + 1], v2 = vp[r * 3 + 2];
 #pragma unroll
           for (int c = 0; c < 6; ++c)
@@ -833,30 +817,31 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_lds(DevProblem d) {
     DBG_STAMP()
   }
   DBG_STAMP()
-  // sum the tps lanes of every slot: guarded shuffle-down tree (fixed order,
-  // any tps <= 32), result in the slot's first lane; 288 + 48 B stored per slot
+  // sum the tps/2 lanes of every half slot: guarded shuffle-down tree over the
+  // lanes of equal h (stride 2; fixed order, any tps/2 <= 16), result in the
+  // half's first lane
 #pragma unroll
-  for (int k = 0; k < 42; ++k) {
-    double a2 = k < 36 ? acc[k] : racc[k - 36];
-    int w = tps;
+  for (int k = 0; k < 21; ++k) {
+    double a2 = k < 18 ? acc[k] : racc[k - 18];
+    int w = tps2;
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-      const double o2 = __shfl_down(a2, off, 64);
-      if (sub + off < w) a2 += o2;
+    for (int off = 8; off >= 1; off >>= 1) {
+      const double o2 = __shfl_down(a2, 2 * off, 64);
+      if (sub2 + off < w) a2 += o2;
       w = w < off ? w : off;
     }
-    if (k < 36) acc[k] = a2; else racc[k - 36] = a2;
+    if (k < 18) acc[k] = a2; else racc[k - 18] = a2;
   }
 #ifdef BA_SCHUR_DBG
   if (dbg_on)
     for (int k = 0; k < 160; ++k) g_schur_dbg[dbg_slot][k] = k < dbg_n ? dbg_s[k] : 0;
 #endif
-  if (owner && sub == 0) {
+  if (owner && sub2 == 0) {  // 144 + 24 B per half slot
     double *o = d.spart2 + (size_t)(sd.s0 + slot) * kSlotStride;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) o[k] = acc[k];
+    for (int k = 0; k < 18; ++k) o[h * 18 + k] = acc[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[36 + k] = racc[k];
+    for (int k = 0; k < 3; ++k) o[36 + h * 3 + k] = racc[k];
   }
 }
 
@@ -914,26 +899,39 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
 // :878-888).  One workgroup per block: 7 parts x 36
 // entries; part q sums every 7th slot partial of the block, the parts are then
 // added in order 0..6 (fixed tree: deterministic).
+// One workgroup per block: 6 parts x 42 entries (36 of S; for a diagonal block
+// also the 6 of B Cinv b that ride behind them in every slot partial).  Part q
+// sums every 6th slot partial of the block, the parts are then added in order
+// 0..5 (fixed tree: deterministic).  rhs_j = a_j - B Cinv b (reference :887-888)
+// goes behind the S blocks of the packed buffer.
 template <bool DIRECT>
 __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t blk,
-                                                 double (*part)[36]) {
-  const int q = threadIdx.x / 36, e = threadIdx.x - q * 36;
-  if (q < 7) {
+                                                 double (*part)[42]) {
+  const int q = threadIdx.x / 42, e = threadIdx.x - q * 42;
+  const int j = d.sblk_j[blk], k = d.sblk_k[blk];
+  if (q < 6 && (e < 36 || j == k)) {
     double s = 0.0;
     const int64_t c1 = d.blk_contrib_ptr[blk + 1];
-    for (int64_t cidx = d.blk_contrib_ptr[blk] + q; cidx < c1; cidx += 7)
+    for (int64_t cidx = d.blk_contrib_ptr[blk] + q; cidx < c1; cidx += 6)
       s += d.spart2[(size_t)d.contrib_slot[cidx] * kSlotStride + e];
     const int ch1 = d.sblk_tchunk_ptr[blk + 1];
-    for (int ch = d.sblk_tchunk_ptr[blk] + q; ch < ch1; ch += 7)
+    for (int ch = d.sblk_tchunk_ptr[blk] + q; ch < ch1; ch += 6)
       s += d.spart[(size_t)ch * kSlotStride + e];
     part[q][e] = s;
   }
   __syncthreads();
-  if (threadIdx.x >= 36) return;
+  if (threadIdx.x >= 42 || (e >= 36 && j != k)) return;
   double s = part[0][e];
 #pragma unroll
-  for (int k = 1; k < 7; ++k) s += part[k][e];
-  const int j = d.sblk_j[blk], k = d.sblk_k[blk];
+  for (int p = 1; p < 6; ++p) s += part[p][e];
+  if (e >= 36) {  // rhs of pose j
+    const int r = e - 36;
+    const double val = d.a[(size_t)j * 6 + r] - s;
+    d.Spk[(size_t)d.B * 36 + (size_t)j * 6 + r] = val;
+    if (DIRECT)  // rhs rides as row `npad` of the dense matrix (see k_scatter)
+      d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = val;
+    return;
+  }
   const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
   d.Spk[(size_t)blk * 36 + e] = val;
   if (DIRECT) {  // same placement as k_scatter
@@ -950,18 +948,15 @@ __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t bl
 }
 __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
   if (d.ctrl->done) return;
-  __shared__ double part[7][36];
+  __shared__ double part[6][42];
   schur_final_body<false>(d, blockIdx.x, part);
 }
-// Single GPU: blocks of S, rhs and their placement in the dense matrix in one
-// launch (the packed buffer is still written: the readers use it).
+// Single GPU: the same, and every value is also placed in the dense matrix
+// (the packed buffer is still written: the readers use it).
 __global__ __launch_bounds__(kBlock) void k_schur_final_direct(DevProblem d) {
   if (d.ctrl->done) return;
-  __shared__ double part[7][36];
-  if ((int64_t)blockIdx.x < d.B)
-    schur_final_body<true>(d, blockIdx.x, part);
-  else
-    rhs_final_body<true>(d, (int)(blockIdx.x - d.B) * kBlock + threadIdx.x);
+  __shared__ double part[6][42];
+  schur_final_body<true>(d, blockIdx.x, part);
 }
 
 // Packed S blocks and rhs -> dense column-major lower matrix (reference
@@ -1395,8 +1390,6 @@ void launch_schur(const DevProblem &d, hipStream_t s) {
     BA_LAUNCH(K_SCHUR_LDS, k_schur_lds, dim3(d.n_sup), dim3(kBlock), s, d);
   if (d.n_tchunk > 0)
     BA_LAUNCH(K_SCHUR_PARTIAL, k_schur_partial, dim3(d.n_tchunk), dim3(64), s, d);
-  if (d.N > 0)
-    BA_LAUNCH(K_RHS_FINAL, k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)), dim3(kBlock), s, d);
   if (d.B > 0)
     BA_LAUNCH(K_SCHUR_FINAL, k_schur_final, dim3((unsigned)d.B), dim3(kBlock), s,
                        d);
@@ -1404,7 +1397,7 @@ void launch_schur(const DevProblem &d, hipStream_t s) {
 
 // linearisation + Schur complement with the pose side on a second stream: the
 // pose-side sums (A_j, a_j) and the reset of the factor tiles depend only on
-// the current parameters and are first needed by k_rhs_final / k_schur_final,
+// the current parameters and are first needed by k_schur_final,
 // so they run beside k_lin_landmarks and k_schur_lds instead of after them.
 void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
                                        hipStream_t s2, hipEvent_t fork,
@@ -1432,14 +1425,12 @@ void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
   if (d.n_tchunk > 0)
     hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
   (void)hipStreamWaitEvent(s, join, 0);
-  if (direct) {
-    hipLaunchKernelGGL(k_schur_final_direct,
-                       dim3((unsigned)(d.B + cdiv((int64_t)d.N * 6, kBlock))), dim3(kBlock), 0, s, d);
-    return;
+  if (d.B > 0) {
+    if (direct)
+      hipLaunchKernelGGL(k_schur_final_direct, dim3((unsigned)d.B), dim3(kBlock), 0, s, d);
+    else
+      hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s, d);
   }
-  if (d.N > 0)
-    hipLaunchKernelGGL(k_rhs_final, dim3(cdiv((int64_t)d.N * 6, kBlock)), dim3(kBlock), 0, s, d);
-  if (d.B > 0) hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s, d);
 }
 
 // back-substitution with the pose update (needs x only) on the second stream

@@ -382,11 +382,27 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       // ---- grow a super-run ----
       const int i0 = i;
       sup_blocks.clear();
+      // chunk count of the run so far (same greedy rule as the chunk loop below)
+      int nchunk = 1, cnl = 0;
+      int64_t cnp = 0, cnt = 0;
       while (i < M && i - i0 < kSchurSuperLandmarks) {
         const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
         if (is_big(p1 - p0)) {
           if (i == i0) ++i;  // big landmark alone (handled by the triple list)
           break;
+        }
+        {
+          const int64_t dd = p1 - p0, dt = dd * (dd + 1) / 2;
+          if (cnl > 0 && (cnp + dd > kSchurPairs || cnt + dt > kSchurTri ||
+                          cnl >= kSchurLandmarks)) {
+            if (nchunk == kSchurSuperChunks) break;  // descriptor table in LDS is full
+            ++nchunk;
+            cnp = cnt = 0;
+            cnl = 0;
+          }
+          cnp += dd;
+          cnt += dt;
+          ++cnl;
         }
         // blocks this landmark would add
         const size_t before = sup_blocks.size();
@@ -473,6 +489,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         pl.chunk_desc.push_back(cd);
       }
       sd.chunk_end = (int32_t)pl.chunk_desc.size();
+      if (sd.chunk_end - sd.chunk_begin > kSchurSuperChunks)
+        return "internal: super-run exceeds kSchurSuperChunks chunks";
       pl.sup_desc.push_back(sd);
       for (int32_t bk : sup_blocks) mark[bk] = -1;
     }

@@ -43,7 +43,8 @@ constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
 constexpr int kSchurLandmarks = 128;  // landmarks per chunk
 constexpr int kSchurTri = 1024;       // triples per chunk (LDS resident)
 constexpr int kSchurSlots = 128;      // distinct blocks per super-run (>= 2 lanes each)
-constexpr int kSchurSuperLandmarks = 512;  // landmarks per super-run
+constexpr int kSchurSuperLandmarks = 256;  // landmarks per super-run
+constexpr int kSchurSuperChunks = 64;      // chunks per super-run (descriptor table in LDS)
 
 struct Plan {
   // ---- sizes ----
