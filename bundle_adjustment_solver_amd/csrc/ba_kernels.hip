@@ -113,6 +113,7 @@ __device__ __forceinline__ void project(const double *__restrict__ cam,
                                         const double X0, const double X1,
                                         const double X2, const double u,
                                         const double v, ObsGeom &g) {
+#pragma clang fp contract(fast)
 #pragma unroll
   for (int r = 0; r < 3; ++r)
     g.Xij[r] = (T[r * 3 + 0] * X0 + T[r * 3 + 1] * X1 + T[r * 3 + 2] * X2) +
@@ -133,6 +134,7 @@ __device__ __forceinline__ void project(const double *__restrict__ cam,
 __device__ __forceinline__ void weight_and_G(const double *__restrict__ cam,
                                              const ObsGeom &g, double huber,
                                              double &w, double G[6]) {
+#pragma clang fp contract(fast)
   const double invz = 1.0 / g.Xc[2];
   const double fxinvz = cam[0] * invz, fyinvz = cam[1] * invz;
   const double xinvz = g.Xc[0] * invz, yinvz = g.Xc[1] * invz;
@@ -151,6 +153,7 @@ __device__ __forceinline__ void weight_and_G(const double *__restrict__ cam,
 // Q = [G, G * (-[Xij]x)]  (reference :797-800), 2x6 row-major
 __device__ __forceinline__ void make_Q(const double G[6], const double Xij[3],
                                        double Q[12]) {
+#pragma clang fp contract(fast)
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const double g0 = G[r * 3 + 0], g1 = G[r * 3 + 1], g2 = G[r * 3 + 2];
@@ -167,6 +170,7 @@ __device__ __forceinline__ void make_Q(const double G[6], const double Xij[3],
 __device__ __forceinline__ void make_R(const double G[6],
                                        const double *__restrict__ T,
                                        double Rm[6]) {
+#pragma clang fp contract(fast)
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -396,6 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
       uv = d.obs_uv[s];
     }
     if (s < oe) {
+#pragma clang fp contract(fast)
       double cam[16];
       load_cam<LDSCAM>(d, cams_s, id.x, cam);
       const double *T = poses + (size_t)id.y * 12;
@@ -500,10 +505,10 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
     int k = 0;                                                                  \
     _Pragma("unroll") for (int r = 0; r < 6; ++r)                               \
     _Pragma("unroll") for (int c = r; c < 6; ++c)                               \
-      acc[k++] += (w * Q[r]) * Q[c] + (w * Q[6 + r]) * Q[6 + c];                \
+      { acc[k] = fma(w * Q[r], Q[c], fma(w * Q[6 + r], Q[6 + c], acc[k])); ++k; } \
     const double wr0 = w * g.r0, wr1 = w * g.r1;                                \
     _Pragma("unroll") for (int c = 0; c < 6; ++c)                               \
-      acc[21 + c] += Q[c] * wr0 + Q[6 + c] * wr1;                               \
+      acc[21 + c] = fma(Q[c], wr0, fma(Q[6 + c], wr1, acc[21 + c]));            \
     ccam = ncam_;                                                               \
     cuv = nuv_;                                                                 \
   }
