@@ -57,10 +57,31 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Wave-wide sum on the DPP network (no LDS round trips): xor-1, xor-2,
+// half-mirror and mirror steps leave every lane with the total of its row of
+// 16, the four row totals are then added in order.  Fixed association:
+// deterministic; every lane returns the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  union { double d; int i[2]; } u, r;
+  u.d = v;
+  r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, false);
+  r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, false);
+  return r.d;
+}
+__device__ __forceinline__ double lane_f64(double v, int src) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return ((lane_f64(v, 0) + lane_f64(v, 16)) + lane_f64(v, 32)) + lane_f64(v, 48);
 }
 
 // Sum over a 256-thread block; result valid in thread 0.  `sm` holds >= 4.
@@ -1020,131 +1041,190 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
 constexpr int kBsRW = (kSchurPairs * 9 + kBlock - 1) / kBlock;
 constexpr int kBsRX = (kSchurPairs * 3 + kBlock - 1) / kBlock;
 
+// Each workgroup handles kBsChunks consecutive chunks: while chunk k goes
+// through its LDS phases, the W blocks and pose indices of chunk k+1 are already
+// in flight (into the registers chunk k has just released), so only the first
+// chunk of a workgroup pays the full load latency.
+constexpr int kBsChunks = 4;
+#ifdef BA_BS_DBG
+__device__ long long g_bs_dbg[96];
+#define BS_STAMP() { if (bs_on && bs_n < 96) bs_s[bs_n++] = clock64(); }
+#else
+#define BS_STAMP()
+#endif
 __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
   __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Xs[kSchurPairs * 6];
   __shared__ double Us[kSchurPairs * 3];
   __shared__ double sm[4];
-  const DevProblem::LmChunk lc = d.lm_chunk[blockIdx.x];
+  __shared__ int recs[kBsChunks * 8];
+  const int tid = threadIdx.x;
+#ifdef BA_BS_DBG
+  __shared__ long long bs_s[96];
+  const bool bs_on = blockIdx.x == 2000 && threadIdx.x == 0;
+  int bs_n = 0;
+#endif
+  BS_STAMP()
+  const int c0 = blockIdx.x * kBsChunks;
+  const int nk = min(kBsChunks, d.n_bchunk - c0);
+  // the workgroup's chunk records -> LDS (vector loads), first one also scalar
+  const DevProblem::LmChunk lc0 = d.lm_chunk[c0];
+  if (tid < nk * 8) recs[tid] = ((const int *)d.lm_chunk)[(size_t)c0 * 8 + tid];
   const int done = d.ctrl->done;
   const int cur = d.ctrl->cur;
-  BA_KEEP_S((int)lc.pb);
-  BA_KEEP_S(lc.l0);
-  BA_KEEP_S(lc.np);
+  BA_KEEP_S((int)lc0.pb);
+  BA_KEEP_S(lc0.np);
   BA_KEEP_S(done);
   if (done) return;
-  const int tid = threadIdx.x;
   const double *__restrict__ Xc = d.pts[cur];
   double *__restrict__ Xt = d.pts[cur ^ 1];
-  const int64_t pe = lc.pb + lc.np;
-  int64_t t0 = lc.pb;
-  int np = lc.np < kSchurPairs ? lc.np : kSchurPairs;
   double2 rw[kBsRW];
   int rpj[kBsRX];
-  BACKSUB_ISSUE(t0, np)
-  // the landmark owned by this thread (if any): its data is needed last but
-  // depends only on the chunk record, so it is requested now
-  const int i = lc.l0 + tid;
-  const bool own = tid < lc.nl;
-  int64_t q0 = 0, q1 = 0;
-  double ci[6], cb[3], Xi[3], bi[3], C[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) ci[k] = C[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) cb[k] = Xi[k] = bi[k] = 0.0;
-  if (own) {
-    q0 = d.lm_pair_ptr[i];
-    q1 = d.lm_pair_ptr[i + 1];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ci[k] = d.Cinv[(size_t)i * 6 + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cb[k] = d.Cinvb[(size_t)i * 3 + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) Xi[k] = Xc[(size_t)i * 3 + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) bi[k] = d.b[(size_t)i * 3 + k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) C[k] = d.Cd[(size_t)i * 6 + k];
+  // record of the chunk whose W is in the registers
+  int64_t r_pb = lc0.pb;
+  int r_l0 = lc0.l0, r_nl = lc0.nl, r_np = lc0.np;
+  {
+    const int np0 = r_np < kSchurPairs ? r_np : kSchurPairs;
+    BACKSUB_ISSUE(r_pb, np0)
   }
-  double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
-  for (;;) {
-    // x_j gather: lane (pair, c) fetches x_j[2c], x_j[2c+1]
-    double2 rx[kBsRX];
+  __syncthreads();  // recs
+  BS_STAMP()
+  for (int k = 0; k < nk; ++k) {
+    const int64_t pb = r_pb, pe = r_pb + r_np;
+    const int l0 = r_l0, nl = r_nl;
+    // the landmark owned by this thread (if any): its data is needed last but
+    // depends only on the chunk record, so it is requested now
+    const int i = l0 + tid;
+    const bool own = tid < nl;
+    int64_t q0 = 0, q1 = 0;
+    double ci[6], cb[3], Xi[3], bi[3], C[6];
 #pragma unroll
-    for (int k = 0; k < kBsRX; ++k) {
-      const int t = tid + k * kBlock;
-      const int c = t - (t / 3) * 3;
-      rx[k] = (t < np * 3) ? *(const double2 *)(d.x + (size_t)rpj[k] * 6 + 2 * c)
-                           : make_double2(0.0, 0.0);
-    }
-    {
-      double2 *dst = (double2 *)Ws;
+    for (int e = 0; e < 6; ++e) ci[e] = C[e] = 0.0;
 #pragma unroll
-      for (int k = 0; k < kBsRW; ++k) {
-        const int t = tid + k * kBlock;
-        if (t < np * 9) dst[t] = rw[k];
-      }
-      double2 *xd = (double2 *)Xs;
-#pragma unroll
-      for (int k = 0; k < kBsRX; ++k) {
-        const int t = tid + k * kBlock;
-        if (t < np * 3) xd[t] = rx[k];
-      }
-    }
-    __syncthreads();
-    for (int t = tid; t < np * 3; t += kBlock) {
-      const int lp = t / 3, c = t - lp * 3;
-      const double *xj = Xs + lp * 6;
-      const double *w = Ws + lp * 18 + c;
-      double u = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) u = fma(w[r * 3], xj[r], u);
-      Us[t] = u;
-    }
-    __syncthreads();
+    for (int e = 0; e < 3; ++e) cb[e] = Xi[e] = bi[e] = 0.0;
     if (own) {
-      const int64_t a = max(q0, t0), b = min(q1, t0 + np);
-      for (int64_t p = a; p < b; ++p) {
-        const double *u = Us + (p - t0) * 3;
-        bx0 += u[0];
-        bx1 += u[1];
-        bx2 += u[2];
-      }
+      q0 = d.lm_pair_ptr[i];
+      q1 = d.lm_pair_ptr[i + 1];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) ci[e] = d.Cinv[(size_t)i * 6 + e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) cb[e] = d.Cinvb[(size_t)i * 3 + e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Xi[e] = Xc[(size_t)i * 3 + e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) bi[e] = d.b[(size_t)i * 3 + e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) C[e] = d.Cd[(size_t)i * 6 + e];
     }
-    t0 += kSchurPairs;
-    if (t0 >= pe) break;  // uniform
-    np = (int)min((int64_t)kSchurPairs, pe - t0);
-    __syncthreads();  // LDS is rewritten
-    BACKSUB_ISSUE(t0, np)
+    BS_STAMP()
+    double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
+    int64_t t0 = pb;
+    int np = (int)min((int64_t)kSchurPairs, pe - t0);
+    for (;;) {
+      // x_j gather: lane (pair, c) fetches x_j[2c], x_j[2c+1]
+      double2 rx[kBsRX];
+#pragma unroll
+      for (int q = 0; q < kBsRX; ++q) {
+        const int t = tid + q * kBlock;
+        const int c = t - (t / 3) * 3;
+        rx[q] = (t < np * 3) ? *(const double2 *)(d.x + (size_t)rpj[q] * 6 + 2 * c)
+                             : make_double2(0.0, 0.0);
+      }
+      {
+        double2 *dst = (double2 *)Ws;
+#pragma unroll
+        for (int q = 0; q < kBsRW; ++q) {
+          const int t = tid + q * kBlock;
+          if (t < np * 9) dst[t] = rw[q];
+        }
+        double2 *xd = (double2 *)Xs;
+#pragma unroll
+        for (int q = 0; q < kBsRX; ++q) {
+          const int t = tid + q * kBlock;
+          if (t < np * 3) xd[t] = rx[q];
+        }
+      }
+      BS_STAMP()
+      const bool last_tile = t0 + kSchurPairs >= pe;
+      if (last_tile && k + 1 < nk) {  // next chunk's loads fly during this one's phases
+        const int *rr = recs + (k + 1) * 8;
+        r_pb = uni64(*(const int64_t *)rr);
+        r_l0 = __builtin_amdgcn_readfirstlane(rr[4]);
+        r_nl = __builtin_amdgcn_readfirstlane(rr[5]);
+        r_np = __builtin_amdgcn_readfirstlane(rr[6]);
+        const int npn = r_np < kSchurPairs ? r_np : kSchurPairs;
+        BACKSUB_ISSUE(r_pb, npn)
+      }
+      BS_STAMP()
+      __syncthreads();
+      BS_STAMP()
+      for (int t = tid; t < np * 3; t += kBlock) {
+        const int lp = t / 3, c = t - lp * 3;
+        const double *xj = Xs + lp * 6;
+        const double *w = Ws + lp * 18 + c;
+        double u = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) u = fma(w[r * 3], xj[r], u);
+        Us[t] = u;
+      }
+      BS_STAMP()
+      __syncthreads();
+      BS_STAMP()
+      if (own) {
+        const int64_t a = max(q0, t0), b = min(q1, t0 + np);
+        for (int64_t p = a; p < b; ++p) {
+          const double *u = Us + (p - t0) * 3;
+          bx0 += u[0];
+          bx1 += u[1];
+          bx2 += u[2];
+        }
+      }
+      BS_STAMP()
+      if (last_tile) break;  // uniform
+      t0 += kSchurPairs;
+      np = (int)min((int64_t)kSchurPairs, pe - t0);
+      __syncthreads();  // LDS is rewritten
+      BACKSUB_ISSUE(t0, np)
+    }
+    double est = 0.0, nrm = 0.0;
+    if (own) {
+      const double y0 = cb[0] - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);
+      const double y1 = cb[1] - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);
+      const double y2 = cb[2] - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);
+      double *yo = d.y + (size_t)i * 3;
+      yo[0] = y0; yo[1] = y1; yo[2] = y2;
+      double *Xo = Xt + (size_t)i * 3;
+      Xo[0] = Xi[0] + y0;
+      Xo[1] = Xi[1] + y1;
+      Xo[2] = Xi[2] + y2;
+      // reference :443-452 with the damped C_i
+      double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;
+      const double r0 = y0 * C[0] + y1 * C[1] + y2 * C[2];
+      const double r1 = y0 * C[1] + y1 * C[3] + y2 * C[4];
+      const double r2 = y0 * C[2] + y1 * C[4] + y2 * C[5];
+      e += r0 * y0 + r1 * y1 + r2 * y2;
+      e += 2.0 * (y0 * bx0 + y1 * bx1 + y2 * bx2);
+      est = e;
+      nrm = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
+    }
+    BS_STAMP()
+    const double s0 = block_sum(est, sm);
+    const double s1 = block_sum(nrm, sm);
+    if (tid == 0) {
+      d.lm_part[2 * (c0 + k) + 0] = s0;
+      d.lm_part[2 * (c0 + k) + 1] = s1;
+    }
+    BS_STAMP()
   }
-  double est = 0.0, nrm = 0.0;
-  if (own) {
-    const double y0 = cb[0] - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);
-    const double y1 = cb[1] - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);
-    const double y2 = cb[2] - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);
-    double *yo = d.y + (size_t)i * 3;
-    yo[0] = y0; yo[1] = y1; yo[2] = y2;
-    double *Xo = Xt + (size_t)i * 3;
-    Xo[0] = Xi[0] + y0;
-    Xo[1] = Xi[1] + y1;
-    Xo[2] = Xi[2] + y2;
-    // reference :443-452 with the damped C_i
-    double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;
-    const double r0 = y0 * C[0] + y1 * C[1] + y2 * C[2];
-    const double r1 = y0 * C[1] + y1 * C[3] + y2 * C[4];
-    const double r2 = y0 * C[2] + y1 * C[4] + y2 * C[5];
-    e += r0 * y0 + r1 * y1 + r2 * y2;
-    e += 2.0 * (y0 * bx0 + y1 * bx1 + y2 * bx2);
-    est = e;
-    nrm = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
-  }
-  const double s0 = block_sum(est, sm);
-  const double s1 = block_sum(nrm, sm);
-  if (tid == 0) {
-    d.lm_part[2 * blockIdx.x + 0] = s0;
-    d.lm_part[2 * blockIdx.x + 1] = s1;
-  }
+#ifdef BA_BS_DBG
+  if (bs_on) for (int q = 0; q < 96; ++q) g_bs_dbg[q] = q < bs_n ? bs_s[q] : 0;
+#endif
 }
+#ifdef BA_BS_DBG
+extern "C" int ba_debug_read_bs(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_dbg), sizeof(long long) * 96);
+}
+#endif
 
 // se3 exponential (reference :1046-1082) composed onto T_jw (:487-494),
 // pose-side model terms (:437-441) and sum |x_j| (:962).  Block b writes its
@@ -1447,7 +1527,7 @@ void launch_backsub_update_overlapped(const DevProblem &d, hipStream_t s,
   hipLaunchKernelGGL(k_pose_update, dim3(kPoseGrid), dim3(kBlock), 0, s2, d);
   (void)hipEventRecord(join, s2);
   if (d.n_bchunk > 0)
-    hipLaunchKernelGGL(k_backsub_update, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(k_backsub_update, dim3(cdiv(d.n_bchunk, kBsChunks)), dim3(kBlock), 0, s, d);
   (void)hipStreamWaitEvent(s, join, 0);
 }
 
@@ -1459,7 +1539,7 @@ void launch_scatter(const DevProblem &d, hipStream_t s) {
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s) {
   if (d.n_bchunk > 0)
-    BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(d.n_bchunk), dim3(kBlock), s, d);
+    BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(cdiv(d.n_bchunk, kBsChunks)), dim3(kBlock), s, d);
   BA_LAUNCH(K_POSE_UPDATE, k_pose_update, dim3(kPoseGrid), dim3(kBlock), s, d);
 }
 
