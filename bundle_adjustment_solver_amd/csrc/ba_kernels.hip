@@ -99,6 +99,24 @@ __device__ __forceinline__ double block_sum(double v, double *sm) {
   return r;
 }
 
+// Two sums over a 256-thread block with one pair of barriers; valid in thread 0.
+// `sm` holds >= 8.
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *sm) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    sm[wv] = a;
+    sm[4 + wv] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    b = ((sm[4] + sm[5]) + sm[6]) + sm[7];
+  }
+}
+
 // The camera table (16 doubles per camera: fx fy cx cy, R_cj row-major, t_cj)
 // is read by every observation: the first kCamLds cameras live in LDS so the
 // per-observation gather does not go to the vector memory pipeline.
@@ -1038,6 +1056,18 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
       rpj[k_] = (t_ < (np_) * 3) ? d.pair_pose[(t0_) + t_ / 3] : 0;             \
     }                                                                           \
   }
+// x_j gather of the tile whose pose indices are in rpj: lane (pair, c) fetches
+// x_j[2c], x_j[2c+1]
+#define BACKSUB_GATHER(np_)                                                     \
+  {                                                                             \
+    _Pragma("unroll") for (int q_ = 0; q_ < kBsRX; ++q_) {                      \
+      const int t_ = tid + q_ * kBlock;                                         \
+      const int c_ = t_ - (t_ / 3) * 3;                                         \
+      rx[q_] = (t_ < (np_) * 3)                                                 \
+                   ? *(const double2 *)(d.x + (size_t)rpj[q_] * 6 + 2 * c_)     \
+                   : make_double2(0.0, 0.0);                                    \
+    }                                                                           \
+  }
 constexpr int kBsRW = (kSchurPairs * 9 + kBlock - 1) / kBlock;
 constexpr int kBsRX = (kSchurPairs * 3 + kBlock - 1) / kBlock;
 
@@ -1056,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
   __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Xs[kSchurPairs * 6];
   __shared__ double Us[kSchurPairs * 3];
-  __shared__ double sm[4];
+  __shared__ double sm[8];
   __shared__ int recs[kBsChunks * 8];
   const int tid = threadIdx.x;
 #ifdef BA_BS_DBG
@@ -1083,9 +1113,11 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
   // record of the chunk whose W is in the registers
   int64_t r_pb = lc0.pb;
   int r_l0 = lc0.l0, r_nl = lc0.nl, r_np = lc0.np;
+  double2 rx[kBsRX];
   {
     const int np0 = r_np < kSchurPairs ? r_np : kSchurPairs;
     BACKSUB_ISSUE(r_pb, np0)
+    BACKSUB_GATHER(np0)
   }
   __syncthreads();  // recs
   BS_STAMP()
@@ -1121,15 +1153,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
     int64_t t0 = pb;
     int np = (int)min((int64_t)kSchurPairs, pe - t0);
     for (;;) {
-      // x_j gather: lane (pair, c) fetches x_j[2c], x_j[2c+1]
-      double2 rx[kBsRX];
-#pragma unroll
-      for (int q = 0; q < kBsRX; ++q) {
-        const int t = tid + q * kBlock;
-        const int c = t - (t / 3) * 3;
-        rx[q] = (t < np * 3) ? *(const double2 *)(d.x + (size_t)rpj[q] * 6 + 2 * c)
-                             : make_double2(0.0, 0.0);
-      }
+      // (rx: the x_j of this tile, gathered one step ahead)
       {
         double2 *dst = (double2 *)Ws;
 #pragma unroll
@@ -1185,6 +1209,11 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
       np = (int)min((int64_t)kSchurPairs, pe - t0);
       __syncthreads();  // LDS is rewritten
       BACKSUB_ISSUE(t0, np)
+      BACKSUB_GATHER(np)
+    }
+    if (k + 1 < nk) {  // the next chunk's pose indices have arrived: its x_j gather
+      const int npn = r_np < kSchurPairs ? r_np : kSchurPairs;
+      BACKSUB_GATHER(npn)
     }
     double est = 0.0, nrm = 0.0;
     if (own) {
@@ -1208,11 +1237,10 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
       nrm = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
     }
     BS_STAMP()
-    const double s0 = block_sum(est, sm);
-    const double s1 = block_sum(nrm, sm);
+    block_sum2(est, nrm, sm);
     if (tid == 0) {
-      d.lm_part[2 * (c0 + k) + 0] = s0;
-      d.lm_part[2 * (c0 + k) + 1] = s1;
+      d.lm_part[2 * (c0 + k) + 0] = est;
+      d.lm_part[2 * (c0 + k) + 1] = nrm;
     }
     BS_STAMP()
   }
