@@ -46,6 +46,32 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
+PMC_SUMMARY = {"C4": "profiles/r01_c4_pmc_fetch_write_v7.txt"}
+
+
+def pmc_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (one --pmc FETCH_SIZE pass, one --pmc WRITE_SIZE pass over this bench, see
+    profiles/): counters are KiB per dispatch; on gfx950 FETCH_SIZE reports half
+    of a wide coalesced read (MI355X_MICROARCH.md, HBM section), so traffic =
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  bench.py cannot collect PMC counters
+    inside its own timed run; None when no summary is committed for the config."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        PMC_SUMMARY.get(config, ""))
+    if not os.path.isfile(path):
+        return None, None
+    vals = {}
+    for line in open(path):
+        f = line.split()
+        if len(f) >= 4 and f[0].split("<")[0] == kernel and f[1] in (
+                "FETCH_SIZE", "WRITE_SIZE"):
+            vals[f[1]] = float(f[3])
+    if len(vals) != 2:
+        return None, None
+    return ((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,13 +236,15 @@ def main():
             tot = {k: v[0] / n_prof for k, v in km.items() if v[1]}
             dense = sum(tot.get(k, 0.0) for k in
                         ("k_chol_diag", "k_chol_trsm", "k_chol_update",
-                         "k_chol_back"))
+                         "k_chol_back", "k_chol_level"))
             dom = max(kbytes, key=lambda k: tot.get(k, 0.0))
             dom_ms = tot[dom] / km[dom][1] * n_prof   # average launch duration
             ach = kbytes[dom] / (dom_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(dom, args.config)
             result["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": dom, "avg_launch_us": dom_ms * 1e3,
                 "algorithmic_bytes_per_launch": kbytes[dom]}
             result["roofline_all_hbm_kernels"] = {
