@@ -391,11 +391,24 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
 //   pseudo-inverse) and stores Cd, b, Cinv, Cinv b.
 // The W image is written back with contiguous 16-byte stores.
 // --------------------------------------------------------------------------
+#ifdef BA_LL_DBG
+__device__ long long g_ll_dbg[32];
+#define LL_STAMP() { if (ll_on && ll_n < 32) ll_s[ll_n++] = clock64(); }
+#else
+#define LL_STAMP()
+#endif
 template <bool LDSCAM>
 __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
+#ifdef BA_LL_DBG
+  __shared__ long long ll_s[32];
+  const bool ll_on = blockIdx.x == 9000 && threadIdx.x == 0;
+  int ll_n = 0;
+#endif
+  LL_STAMP()
   __shared__ __attribute__((aligned(16))) double Wst[kSchurPairs * 18];
   __shared__ double Cb[kBlock * 9];
   __shared__ double cams_s[kCamLds * 16];
+  __shared__ int lq[kSchurLandmarks + 1];  // landmark observation offsets in the chunk
   // dependent-load chain: chunk record (+ control word) -> observation records
   // (+ this thread's landmark range) -> pose / point gathers
   const DevProblem::LmChunk lc = d.lm_chunk[blockIdx.x];
@@ -421,17 +434,19 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
   }
   const int i = lc.l0 + tid;
   const bool own = tid < lc.nl;
-  int64_t q0 = 0, q1 = 0;
-  if (own) {
-    q0 = d.lm_obs_ptr[i];
-    q1 = d.lm_obs_ptr[i + 1];
-  }
+  int64_t q0 = 0;
+  if (own) q0 = d.lm_obs_ptr[i];
   if (done) return;
+  LL_STAMP()
   const double *__restrict__ poses = d.poses[buf];
   const double *__restrict__ pts = d.pts[buf];
-  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-  double b0 = 0, b1 = 0, b2 = 0;
-  __syncthreads();  // cams_s
+  // landmark observation ranges in LDS; running sums of thread (landmark, value)
+  if (tid <= lc.nl) lq[tid] = (tid < lc.nl) ? (int)(q0 - ob) : lc.no;
+  constexpr int kSumIt = (kSchurLandmarks * 9 + kBlock - 1) / kBlock;
+  double csum[kSumIt];
+#pragma unroll
+  for (int k = 0; k < kSumIt; ++k) csum[k] = 0.0;
+  __syncthreads();  // cams_s, lq
   for (int64_t t0 = ob; t0 < oe; t0 += kBlock) {
     const int64_t s = t0 + tid;
     if (t0 > ob && s < oe) {  // further tiles (more than kBlock observations)
@@ -476,25 +491,66 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
             Wp[r * 3 + c] = w * (Q[r] * Rm[c] + Q[6 + r] * Rm[3 + c]);
       }
     }
+    LL_STAMP()
     __syncthreads();
-    if (own) {
-      const int64_t a = max(q0, t0), b = min(q1, t0 + kBlock);
-      for (int64_t q = a; q < b; ++q) {
-        const double *cb = Cb + (q - t0) * 9;
-        c00 += cb[0]; c01 += cb[1]; c02 += cb[2];
-        c11 += cb[3]; c12 += cb[4]; c22 += cb[5];
-        b0 -= cb[6]; b1 -= cb[7]; b2 -= cb[8];
+    LL_STAMP()
+    // per-landmark sums of this tile, one thread per (landmark, value): nine
+    // times more lanes than one thread per landmark, same insertion order
+    {
+      const int o0 = (int)(t0 - ob);
+#pragma unroll
+      for (int k = 0; k < kSumIt; ++k) {
+        const int t = tid + k * kBlock;
+        if (t < lc.nl * 9) {
+          const int li = t / 9, v = t - li * 9;
+          const int a = max(lq[li], o0), b = min(lq[li + 1], o0 + kBlock);
+          double sacc = 0.0;
+          for (int q = a; q < b; ++q) sacc += Cb[(q - o0) * 9 + v];
+          csum[k] += sacc;
+        }
       }
     }
+    LL_STAMP()
     __syncthreads();
+    LL_STAMP()
+  }
+  // sums -> LDS (Cb is free now) -> the landmark's owner thread
+#pragma unroll
+  for (int k = 0; k < kSumIt; ++k) {
+    const int t = tid + k * kBlock;
+    if (t < lc.nl * 9) Cb[t] = csum[k];
+  }
+  __syncthreads();
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  double b0 = 0, b1 = 0, b2 = 0;
+  if (own) {
+    const double *cs = Cb + tid * 9;
+    c00 = cs[0]; c01 = cs[1]; c02 = cs[2];
+    c11 = cs[3]; c12 = cs[4]; c22 = cs[5];
+    b0 = -cs[6]; b1 = -cs[7]; b2 = -cs[8];
   }
   // W image -> global (contiguous)
   {
     const int n2 = min(npair, kSchurPairs) * 9;
     const double2 *src = (const double2 *)Wst;
     double2 *dst = (double2 *)(d.W + (size_t)pb * 18);
-    for (int t = tid; t < n2; t += kBlock) dst[t] = src[t];
+    constexpr int kIt = (kSchurPairs * 9 + kBlock - 1) / kBlock;
+    double2 wv[kIt];
+#pragma unroll
+    for (int k = 0; k < kIt; ++k) {
+      const int t = tid + k * kBlock;
+      wv[k] = src[t < n2 ? t : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < kIt; ++k) {
+      const int t = tid + k * kBlock;
+      if (t < n2) dst[t] = wv[k];
+    }
   }
+  LL_STAMP()
+#ifdef BA_LL_DBG
+  if (ll_on) { for (int q = 0; q < 32; ++q) g_ll_dbg[q] = q < ll_n ? ll_s[q] : 0; }
+#endif
   if (!own) return;
   // reference :846-856
   double cd[6] = {c00 * lp1, c01, c02, c11 * lp1, c12, c22 * lp1};
@@ -1492,6 +1548,11 @@ void launch_linearize(const DevProblem &d, hipStream_t s) {
     BA_LAUNCH(K_POSE_FINALIZE, k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), s, d);
 }
 
+#ifdef BA_LL_DBG
+extern "C" int ba_debug_read_ll(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ll_dbg), sizeof(long long) * 32);
+}
+#endif
 #ifdef BA_SCHUR_DBG
 extern "C" int ba_debug_read(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_dbg), sizeof(long long) * 4 * 160);

@@ -371,3 +371,31 @@ def test_all_points_fixed_and_single_free_pose(built):
     assert relerr(g.get_poses(), o.get_poses()) < 1e-6
     sc = scenes.hover_scene(3, 50, 1, seed=25, n_fixed=2)
     _compare_solve(scenes.scaled_problem(sc), iters=5)
+
+
+def test_all_poses_fixed_and_no_observations(built):
+    """Degenerate sizes: no optimisable pose (the reduced system is empty, only
+    the landmarks move) and no observation at all (nothing moves; the control
+    step sees a 0/0 gain ratio exactly like the oracle)."""
+    sc = scenes.hover_scene(5, 60, 2, seed=26)
+    sc["pose_fixed"][:] = True
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    rows, _ = g.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0, cls=BaOptions))
+    orows, _ = o.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0))
+    assert len(rows) == len(orows)
+    for a, b in zip(rows, orows):
+        assert a.iteration_status == b.iteration_status
+        assert relerr(a.trial_cost, b.trial_cost) < 1e-7
+    assert relerr(g.get_points()[0], o.get_points()) < 1e-6
+    assert np.array_equal(g.get_poses(), pr["pose_T"])
+    sc = scenes.hover_scene(4, 20, 1, seed=27)
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        sc[k] = sc[k][:0]
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    rows, _ = g.solve(O.make_options(max_iter=3, thr_step=0, thr_cost=0, cls=BaOptions))
+    orows, _ = o.solve(O.make_options(max_iter=3, thr_step=0, thr_cost=0))
+    assert [r.iteration_status for r in rows] == [r.iteration_status for r in orows]
+    assert np.array_equal(g.get_points()[0], pr["pt_X"])
+    assert np.array_equal(g.get_poses(), pr["pose_T"])

@@ -1,0 +1,25 @@
+"""Developer tool: phase time stamps of k_lin_landmarks (workgroup 9000).
+Needs libba_hip.so built with -DBA_LL_DBG."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bundle_adjustment_solver_amd import scenes, _lib
+from bundle_adjustment_solver_amd.solver import BaProblem
+sc = scenes.config_scene("C4")
+pr = scenes.scaled_problem(sc)
+p = BaProblem(0)
+p.set_cameras(pr["cam_intr"], pr["cam_T"]); p.set_poses(pr["pose_T"], pr["pose_fixed"])
+p.set_points(pr["pt_X"], pr["pt_fixed"])
+p.set_observations(pr["obs_cam"], pr["obs_pose"], pr["obs_pt"], pr["obs_uv"])
+p.finalize()
+for _ in range(3):
+    p.stage_linearize(100.0, 1.0)
+lib = _lib.load()
+out = (ctypes.c_longlong * 32)()
+lib.ba_debug_read_ll.argtypes = [ctypes.c_void_p]
+print("rc", lib.ba_debug_read_ll(out))
+t = np.array(out[:]); n = int((t != 0).sum()); d = np.diff(t[:n])
+names = ["record+ctrl+issue", "gathers+compute+lds", "bar1", "own sum", "bar2", "W store issue"]
+print("total", t[n - 1] - t[0])
+for k in range(n - 1):
+    print("  %-22s %6d" % (names[k] if k < len(names) else "?", d[k]))
