@@ -491,27 +491,47 @@ int ba_finalize(ba_handle *h) {
   d.log_cap = 4096;
   if (h->dalloc(&d.log, (size_t)d.log_cap)) return -1;
 
-  // dense reduced system: tiles of kPosesPerTile poses (60 columns + 4 pad),
-  // eliminated in the order of the level schedule
+  // dense reduced system: tiles of 5 poses (32 columns) or 10 poses (64
+  // columns), eliminated in the order of the level schedule.  The solve is a
+  // chain of dependent launches, one set per level, whose cost is a fixed
+  // latency plus a term proportional to the tile order (C4 on MI355X: 31 us
+  // per level at 32, 47 us at 64): both schedules are built and the cheaper
+  // chain wins (BA_DENSE_NB=32|64 forces one).
   {
-    const int ncb = pl.ncb;
     const char *nat = getenv("BA_DENSE_NATURAL");
     const char *full = getenv("BA_DENSE_FULL");
-    std::vector<uint8_t> adj(pl.tile_nz);
-    if (full && atoi(full) != 0) std::fill(adj.begin(), adj.end(), 1);
-    ba::build_dense_schedule(ncb, adj, nat && atoi(nat) != 0, h->sched);
-    d.npad = ncb * ba::kDenseNb;
-    d.ld = d.npad + ba::kDenseNb;
+    const char *force = getenv("BA_DENSE_NB");
+    ba::DenseSchedule cand[2];
+    double cost[2];
+    const int orders[2] = {32, 64};
+    const double level_us[2] = {31.0, 47.0};
+    for (int k = 0; k < 2; ++k) {
+      int ncb_k = 0;
+      std::vector<uint8_t> adj;
+      ba::tile_pattern(pl, ba::dense_poses_per_tile(orders[k]), ncb_k, adj);
+      if (full && atoi(full) != 0) std::fill(adj.begin(), adj.end(), 1);
+      ba::build_dense_schedule(ncb_k, adj, nat && atoi(nat) != 0, orders[k], cand[k]);
+      cost[k] = cand[k].nlev * level_us[k];
+    }
+    int pick = cost[1] < cost[0] ? 1 : 0;
+    if (force && atoi(force) == 32) pick = 0;
+    if (force && atoi(force) == 64) pick = 1;
+    h->sched = cand[pick];
+    const int nb = h->sched.nb;
+    const int ppt = ba::dense_poses_per_tile(nb);
+    const int ncb = h->sched.ncb;
+    d.nb = nb;
+    d.npad = ncb * nb;
+    d.ld = d.npad + nb;
     h->xbuf_n[0] = pl.B * 36 + 6 * (int64_t)pl.N;
     h->xbuf_n[1] = 4;
     if (h->dalloc(&d.Spk, (size_t)h->xbuf_n[0])) return -1;
     if (h->dalloc(&d.L, (size_t)d.npad * d.ld)) return -1;
-    if (h->dalloc(&d.Ldiag, (size_t)ncb * ba::kDenseWsPerBlock)) return -1;
+    if (h->dalloc(&d.Ldiag, (size_t)ncb * ba::dense_ws_per_block(nb))) return -1;
     h->pose_col_h.assign(pl.N, 0);
     std::vector<int> col_x((size_t)d.npad, -1);
     for (int j = 0; j < pl.N; ++j) {
-      const int c0 = h->sched.pos_of_tile[j / ba::kPosesPerTile] * ba::kDenseNb +
-                     6 * (j % ba::kPosesPerTile);
+      const int c0 = h->sched.pos_of_tile[j / ppt] * nb + 6 * (j % ppt);
       h->pose_col_h[j] = c0;
       for (int r = 0; r < 6; ++r) col_x[c0 + r] = 6 * j + r;
     }
@@ -527,7 +547,7 @@ int ba_finalize(ba_handle *h) {
       return -1;
     if (sc.fused_ok &&
         (h->upload(&dd.f_desc, sc.f_desc) || h->upload(&dd.f_pend, sc.f_pend) ||
-         h->dalloc(&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * ba::kDenseNb * ba::kDenseNb)))
+         h->dalloc(&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * nb * nb)))
       return -1;
     dd.col_x = d.col_x;
     HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
@@ -968,7 +988,7 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
                        double *x, double *ms) {
   if (!h || n <= 0 || !A || !b || !x) return fail("ba_dense_spd_solve: bad argument");
   if (use_device(h)) return -1;
-  const int nb = ba::kDenseNb;
+  const int nb = 64;  // a dense matrix has one tile per level either way: fewer, larger tiles
   const int ncb = (n + nb - 1) / nb;
   const int npad = ncb * nb;
   const int ld = npad + nb;
@@ -983,7 +1003,7 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
     }
   ba::DenseSchedule sc;
   const char *nat = getenv("BA_DENSE_NATURAL");
-  ba::build_dense_schedule(ncb, adj, nat && atoi(nat) != 0, sc);
+  ba::build_dense_schedule(ncb, adj, nat && atoi(nat) != 0, nb, sc);
   std::vector<int> colmap(npad), col_x(npad, -1);  // original column -> dense column
   for (int c = 0; c < npad; ++c) colmap[c] = sc.pos_of_tile[c / nb] * nb + c % nb;
   std::vector<double> L((size_t)npad * ld, 0.0);
@@ -1014,12 +1034,11 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
     return -1;
   if (sc.fused_ok) {
     if (up(&dd.f_desc, sc.f_desc) || up(&dd.f_pend, sc.f_pend)) return -1;
-    HIP_TRY(hipMalloc((void **)&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * ba::kDenseNb *
-                                             ba::kDenseNb * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * nb * nb * sizeof(double)));
   }
   HIP_TRY(hipMalloc((void **)&dd.xc, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
-  HIP_TRY(hipMalloc((void **)&dD, (size_t)ncb * ba::kDenseWsPerBlock * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&dD, (size_t)ncb * ba::dense_ws_per_block(nb) * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dx, (size_t)npad * sizeof(double)));
   HIP_TRY(hipMemcpy(dL, L.data(), L.size() * sizeof(double), hipMemcpyHostToDevice));
   hipEvent_t e0, e1;

@@ -9,9 +9,10 @@
 namespace ba {
 
 void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj_in,
-                          bool natural_order, DenseSchedule &s) {
+                          bool natural_order, int nb, DenseSchedule &s) {
   const int n = ncb;
   s = DenseSchedule();
+  s.nb = nb;
   s.ncb = n;
   std::vector<uint8_t> A(adj_in);
   auto at = [&](int a, int b) -> uint8_t & { return A[(size_t)a * n + b]; };
@@ -151,7 +152,7 @@ void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj_in,
     long long total = 0;
     for (int p = 0; p < n; ++p) {
       const long long nrow = s.row_ptr[p + 1] - s.row_ptr[p];
-      if (nrow > kMaxFusedRows) s.fused_ok = false;
+      if (nrow > dense_max_fused_rows(nb)) s.fused_ok = false;
       total += nrow * (nrow + 1) / 2 - 1;
     }
     if (total > kMaxContrib) s.fused_ok = false;

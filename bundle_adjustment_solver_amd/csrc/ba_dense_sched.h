@@ -26,11 +26,16 @@
 
 namespace ba {
 
-constexpr int kMaxFusedRows = 12;     // row tiles per source held in LDS
 constexpr int kMaxContrib = 32768;    // contribution tiles (8 KiB each at order 32)
-constexpr int kPosesPerTile = 5;  // 30 columns + 2 padding columns per tile
+// Tile order nb = 32 (5 poses + 2 padding columns) or 64 (10 poses + 4): chosen
+// per problem by ba_finalize from the two level schedules.
+inline int dense_poses_per_tile(int nb) { return nb == 32 ? 5 : 10; }
+inline int dense_ws_per_block(int nb) { return nb * nb + (nb / 16) * 256; }
+// row tiles a fused-level workgroup can keep in LDS (ba_dense_tile.inc: FR)
+inline int dense_max_fused_rows(int nb) { return nb == 32 ? 12 : 3; }
 
 struct DenseSchedule {
+  int nb = 32;    // tile order the schedule was built for
   int ncb = 0;    // tiles (the rhs row block has index ncb)
   int nlev = 0;
   std::vector<int> pos_of_tile;  // original tile/group -> elimination position
@@ -51,7 +56,7 @@ struct DenseSchedule {
   // instead of updating the targets in place; a tile subtracts its pending
   // contributions when it is consumed (as a diagonal tile or as a row tile of
   // the column being eliminated).  Used when every tile has at most
-  // kMaxFusedRows row tiles (incl. the rhs block) and the number of
+  // dense_max_fused_rows(nb) row tiles (incl. the rhs block) and the number of
   // contribution tiles stays below kMaxContrib (banded / block-sparse systems);
   // dense patterns keep the in-place three-kernel path.
   //   f_desc[16 p ..] = { nrow, row_begin, pend_begin, pend_n, out_base, npairs, 0, 0,
@@ -69,7 +74,7 @@ struct DenseSchedule {
 // tiles), row-major bytes.  `natural_order` = keep the given order and put
 // every tile in its own level (debug / dense comparison).
 void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj,
-                          bool natural_order, DenseSchedule &s);
+                          bool natural_order, int nb, DenseSchedule &s);
 
 }  // namespace ba
 #endif

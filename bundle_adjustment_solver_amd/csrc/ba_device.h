@@ -111,7 +111,8 @@ struct DevProblem {
   // dense reduced system: column-major lower, ld rows (rhs rides as row npad)
   double *L;
   int npad, ld;
-  double *Ldiag;   // (npad/64) * kDenseWsPerBlock (diagonal factors + inverses)
+  double *Ldiag;   // (npad/nb) * dense_ws_per_block(nb) (diagonal factors + inverses)
+  int nb;          // tile order of the reduced system (32 or 64)
   int *pose_col;   // N: first dense column of optimised pose j
   int *col_x;      // npad: dense column -> 6*pose + r, or -1 (padding)
   int32_t *bchunk_lm;  // n_bchunk+1 landmark ranges (backsub)
@@ -131,9 +132,7 @@ constexpr int kCostGrid = 1024;
 constexpr int kLmGrid = 1024;
 constexpr int kPoseGrid = 16;
 constexpr int kSlotStride = 42;  // 6x6 block of B Cinv B^T + 6 of B Cinv b
-constexpr int kDenseNb = 32;
 // dense workspace per 64-column block: L11 (64x64) + four 16x16 tile inverses
-constexpr int kDenseWsPerBlock = kDenseNb * kDenseNb + (kDenseNb / 16) * 256;
 
 // ---- optional per-kernel device timing (hipEvents around every launch) ----
 // Enabled by ba_enable_stage_timing: bench.py uses it to measure the average
@@ -216,7 +215,7 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const int *done_flag, const DenseSchedule &sc,
                         const DenseDev &dd, hipStream_t s);
 void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
-                       const int *zt_J, int n_zt, const int *done_flag,
+                       const int *zt_J, int n_zt, int nb, const int *done_flag,
                        hipStream_t s);
 
 // ---- pose-only (ba_pose_only.hip) ----

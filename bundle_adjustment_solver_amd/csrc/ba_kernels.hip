@@ -1559,7 +1559,7 @@ extern "C" int ba_debug_read(long long *out) {
 }
 #endif
 void launch_schur(const DevProblem &d, hipStream_t s) {
-  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, &d.ctrl->done, s);
+  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, s);
   if (d.n_sup > 0)
     BA_LAUNCH(K_SCHUR_LDS, k_schur_lds, dim3(d.n_sup), dim3(kBlock), s, d);
   if (d.n_tchunk > 0)
@@ -1578,7 +1578,7 @@ void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
                                        hipEvent_t join, bool direct) {
   (void)hipEventRecord(fork, s);
   (void)hipStreamWaitEvent(s2, fork, 0);
-  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, &d.ctrl->done, s2);
+  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, s2);
   if (d.n_achunk > 0) {
     if (d.n_cam <= kCamLds)
       hipLaunchKernelGGL(k_lin_poses<true>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), 0, s2, d);

@@ -377,6 +377,10 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     std::vector<int32_t> mark(pl.B, -1);               // block -> local slot
     std::vector<int32_t> sup_blocks;
     std::vector<std::pair<int32_t, uint32_t>> loc;
+    // landmarks per super-run: at most kSchurSuperLandmarks, fewer when the
+    // shard is small, so that there are about three workgroups per CU
+    const int sup_cap = (int)std::min<int64_t>(
+        kSchurSuperLandmarks, std::max<int64_t>(kSchurSuperMin, M / kSchurRunTarget));
     int i = 0;
     while (i < M) {
       // ---- grow a super-run ----
@@ -385,7 +389,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       // chunk count of the run so far (same greedy rule as the chunk loop below)
       int nchunk = 1, cnl = 0;
       int64_t cnp = 0, cnt = 0;
-      while (i < M && i - i0 < kSchurSuperLandmarks) {
+      while (i < M && i - i0 < sup_cap) {
         const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
         if (is_big(p1 - p0)) {
           if (i == i0) ++i;  // big landmark alone (handled by the triple list)
@@ -524,21 +528,21 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     }
   }
 
-  // ---- tile pattern of S (global: every shard factors the same matrix) ----
-  {
-    // tiles = groups of kPosesPerTile consecutive optimised poses
-    pl.ncb = std::max(1, (N + kPosesPerTile - 1) / kPosesPerTile);
-    const int ncb = pl.ncb;
-    pl.tile_nz.assign((size_t)ncb * ncb, 0);
-    for (int t = 0; t < ncb; ++t) pl.tile_nz[(size_t)t * ncb + t] = 1;
-    auto mark = [&](int j, int k) {  // optimised poses j, k are coupled
-      const int a = j / kPosesPerTile, b = k / kPosesPerTile;
-      pl.tile_nz[(size_t)a * ncb + b] = 1;
-      pl.tile_nz[(size_t)b * ncb + a] = 1;
-    };
-    for (int64_t bk = 0; bk < pl.B; ++bk) mark(pl.sblk_j[bk], pl.sblk_k[bk]);
-  }
   return std::string();
+}
+
+// Tile pattern of S for tiles of `poses_per_tile` consecutive optimised poses
+// (global: every shard factors the same matrix).
+void tile_pattern(const Plan &pl, int poses_per_tile, int &ncb,
+                  std::vector<uint8_t> &adj) {
+  ncb = std::max(1, (pl.N + poses_per_tile - 1) / poses_per_tile);
+  adj.assign((size_t)ncb * ncb, 0);
+  for (int t = 0; t < ncb; ++t) adj[(size_t)t * ncb + t] = 1;
+  for (int64_t bk = 0; bk < pl.B; ++bk) {
+    const int a = pl.sblk_j[bk] / poses_per_tile, b = pl.sblk_k[bk] / poses_per_tile;
+    adj[(size_t)a * ncb + b] = 1;
+    adj[(size_t)b * ncb + a] = 1;
+  }
 }
 
 }  // namespace ba

@@ -43,7 +43,9 @@ constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
 constexpr int kSchurLandmarks = 128;  // landmarks per chunk
 constexpr int kSchurTri = 1024;       // triples per chunk (LDS resident)
 constexpr int kSchurSlots = 128;      // distinct blocks per super-run (>= 2 lanes each)
-constexpr int kSchurSuperLandmarks = 256;  // landmarks per super-run
+constexpr int kSchurSuperLandmarks = 256;  // landmarks per super-run (upper bound)
+constexpr int kSchurSuperMin = 32;         // ... lower bound
+constexpr int kSchurRunTarget = 768;       // super-runs aimed at (3 workgroups x 256 CUs)
 constexpr int kSchurSuperChunks = 64;      // chunks per super-run (descriptor table in LDS)
 
 struct Plan {
@@ -114,10 +116,13 @@ struct Plan {
   std::vector<int64_t> blk_contrib_ptr;  // B+1 -> contrib_slot
   std::vector<int32_t> contrib_slot;     // slots of each block, workgroup order
   std::vector<int32_t> bchunk_lm;        // landmark ranges of the backsub chunks
-  // ---- tile pattern of the GLOBAL reduced camera matrix (all shards) ----
-  int ncb = 0;                           // tiles = groups of kPosesPerTile poses
-  std::vector<uint8_t> tile_nz;          // ncb*ncb symmetric adjacency
 };
+
+// Tile pattern of the GLOBAL reduced camera matrix (all shards) for tiles of
+// `poses_per_tile` consecutive optimised poses: ncb tiles, ncb*ncb symmetric
+// adjacency bytes.
+void tile_pattern(const Plan &pl, int poses_per_tile, int &ncb,
+                  std::vector<uint8_t> &adj);
 
 // Owner rank of every point: locality order (first observing optimised pose,
 // then input index), contiguous chunks balanced by observation count.
