@@ -112,6 +112,11 @@ SIGNATURES = {
                                      C.POINTER(BaOptions), C.POINTER(BaPoIter),
                                      C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), _F]),
+    "ba_pose_only_stereo6": (C.c_int, [_P, _F, _F, _F, C.c_int, _F, _F, _F, _F,
+                                       _U8, _U8, C.POINTER(BaOptions),
+                                       C.POINTER(BaPoIter), C.c_int,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       _F]),
 }
 
 _lib = None

@@ -87,6 +87,9 @@ struct ba_handle {
   std::vector<int> pose_col_h;
   // pose-only scratch (grown on demand, reused across calls)
   int po_cap_n = 0, po_cap_it = 0;
+  float *po_uvr = nullptr, *po_camr = nullptr;
+  uint8_t *po_maskr = nullptr;
+  int po_cap_nr = 0;
   float *po_X = nullptr, *po_uv = nullptr, *po_T = nullptr, *po_dbg = nullptr;
   uint8_t *po_mask = nullptr;
   ba::PoIter *po_iters = nullptr;
@@ -1103,6 +1106,81 @@ int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
   HIP_TRY(hipMemcpyAsync(meta, h->po_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(T12, h->po_T, 12 * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(mask, h->po_mask, (size_t)n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
+  const int rows = std::min(meta[2], cap);
+  if (iters && rows > 0)
+    HIP_TRY(hipMemcpy(iters, h->po_iters, (size_t)rows * sizeof(ba_po_iter), hipMemcpyDeviceToHost));
+  if (debug_T12 && meta[0] > 0)
+    HIP_TRY(hipMemcpy(debug_T12, h->po_dbg, (size_t)std::min(meta[0], cap) * 12 * sizeof(float),
+                      hipMemcpyDeviceToHost));
+  if (n_iter) *n_iter = meta[0];
+  if (converged) *converged = meta[1];
+  return meta[3] ? 0 : 1;  // 1 = NaN pose, input left unchanged (reference :159-167)
+}
+
+int ba_pose_only_stereo6(ba_handle *h, const float *X3, const float *uv2,
+                         const float *uvr2, int n, const float *intr_l4,
+                         const float *intr_r4, const float *T_lr12, float *T12,
+                         uint8_t *mask, uint8_t *mask_r, const ba_options *opt,
+                         ba_po_iter *iters, int cap, int *n_iter, int *converged,
+                         float *debug_T12) {
+  if (!h || !X3 || !uv2 || !uvr2 || n <= 0 || !intr_l4 || !intr_r4 || !T_lr12 || !T12 ||
+      !mask || !mask_r || !opt)
+    return fail("ba_pose_only_stereo6: bad argument");
+  const float fx = intr_l4[0], fy = intr_l4[1], cx = intr_l4[2], cy = intr_l4[3];
+  // right camera record: fx fy cx cy, then pose_right_to_left = left_to_right^-1
+  // (reference :226) as R (9, row-major) and t (3)
+  float camr[16];
+  for (int k = 0; k < 4; ++k) camr[k] = intr_r4[k];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) camr[4 + r * 3 + c] = T_lr12[c * 3 + r];
+  for (int r = 0; r < 3; ++r)
+    camr[13 + r] = -(camr[4 + r * 3 + 0] * T_lr12[9] + camr[4 + r * 3 + 1] * T_lr12[10] +
+                     camr[4 + r * 3 + 2] * T_lr12[11]);
+  if (use_device(h)) return -1;
+  static_assert(sizeof(ba::PoIter) == sizeof(ba_po_iter), "po iter layout");
+  const int max_it = opt->max_num_iterations;
+  const int icap = std::max(1, std::max(cap, max_it));
+  if (n > h->po_cap_n) {
+    if (h->dalloc(&h->po_X, (size_t)n * 3) || h->dalloc(&h->po_uv, (size_t)n * 2) ||
+        h->dalloc(&h->po_mask, (size_t)n))
+      return -1;
+    h->po_cap_n = n;
+  }
+  if (n > h->po_cap_nr || !h->po_camr) {
+    if (h->dalloc(&h->po_uvr, (size_t)n * 2) || h->dalloc(&h->po_maskr, (size_t)n) ||
+        (!h->po_camr && h->dalloc(&h->po_camr, (size_t)16)))
+      return -1;
+    h->po_cap_nr = n;
+  }
+  if (icap > h->po_cap_it || !h->po_T) {
+    if (h->dalloc(&h->po_iters, (size_t)icap) || h->dalloc(&h->po_dbg, (size_t)icap * 12))
+      return -1;
+    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4)))
+      return -1;
+    h->po_cap_it = icap;
+  }
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->po_X, X3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_uv, uv2, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_mask, mask, (size_t)n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_T, T12, 12 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_uvr, uvr2, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_maskr, mask_r, (size_t)n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->po_camr, camr, sizeof(camr), hipMemcpyHostToDevice, s));
+  if (ba::pose_only_stereo6_device(h->po_X, h->po_uv, h->po_uvr, n, fx, fy, cx, cy, h->po_camr,
+                                   h->po_T, h->po_mask, h->po_maskr,
+                                 opt->threshold_huber_loss, opt->threshold_step_size,
+                                 opt->threshold_cost_change, opt->threshold_outlier_rejection,
+                                 max_it, h->po_iters, icap, h->po_meta,
+                                 debug_T12 ? h->po_dbg : nullptr, s))
+    return fail("pose-only kernel launch failed");
+  int meta[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(meta, h->po_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(T12, h->po_T, 12 * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(mask, h->po_mask, (size_t)n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(mask_r, h->po_maskr, (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
   const int rows = std::min(meta[2], cap);

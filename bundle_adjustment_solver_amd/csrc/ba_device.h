@@ -228,6 +228,12 @@ int pose_only_mono6_device(const float *dX3, const float *duv2, int n, float fx,
                            float thr_cost, float thr_out, int max_it,
                            PoIter *d_iters, int cap, int *d_meta,
                            float *d_debug, hipStream_t s);
+int pose_only_stereo6_device(const float *dX3, const float *duvl2, const float *duvr2, int n,
+                             float fx, float fy, float cx, float cy, const float *d_cam_r16,
+                             float *dT12, uint8_t *dmask_l, uint8_t *dmask_r, float thr_huber,
+                             float thr_step, float thr_cost, float thr_out, int max_it,
+                             PoIter *d_iters, int cap, int *d_meta, float *d_debug,
+                             hipStream_t s);
 
 }  // namespace ba
 #endif

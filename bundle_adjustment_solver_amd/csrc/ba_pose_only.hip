@@ -1,8 +1,12 @@
-// ba_pose_only.hip — pose-only monocular 6-DoF Gauss-Newton, fp32, gfx950.
+// ba_pose_only.hip — pose-only 6-DoF Gauss-Newton (monocular and stereo), fp32,
+// gfx950.
 //
 // Replaces PoseOnlyBundleAdjustmentSolver::Solve_Monocular_6Dof (reference
 // core/pose_only_bundle_adjustment_solver.cpp:8-170 with helpers :1338-1452,
-// :1147-1200, :1280-1316).  The whole GN loop runs inside ONE persistent
+// :1147-1200, :1280-1316) and ::Solve_Stereo_6Dof (:172-399: the right camera
+// sees X_r = left_to_right^-1 * X_l, contributes where its pixel is
+// non-negative, has its own inlier mask; the error is normalised by
+// (count_left + count_right) * 0.5f).  The whole GN loop runs inside ONE persistent
 // workgroup launch (the problem is 10 k points ~ 200 KB: launch / PCIe latency
 // dominates, not bandwidth): per iteration every thread linearises its points,
 // the 21+6+1 sums are reduced through shuffles + LDS, thread 0 solves the 6x6
@@ -22,7 +26,7 @@ namespace {
 
 constexpr int kPoThreads = 1024;
 constexpr int kPoWaves = kPoThreads / 64;
-constexpr int kNred = 28;  // 21 upper H + 6 g + 1 err
+constexpr int kNred = 29;  // 21 upper H + 6 g + 1 err + 1 count of right-camera edges
 
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
@@ -107,11 +111,53 @@ __device__ void ldlt6_solve(float *m /*36, row-major, lower used*/, float *d) {
 #undef AT
 }
 
+// One camera's terms of one point (reference :1350-1452) added to acc.
+__device__ __forceinline__ void po_edge(const float Lp[3], float fx, float fy, float cx,
+                                        float cy, float pu, float pv, float thr_huber,
+                                        float thr_out, float acc[kNred], uint8_t *mk) {
+  // reference :1350-1384
+  const float iz = 1.0f / Lp[2];
+  const float xiz = Lp[0] * iz, yiz = Lp[1] * iz;
+  const float fxxiz = fx * xiz, fyyiz = fy * yiz;
+  const float ru = (fxxiz + cx) - pu;
+  const float rv = (fyyiz + cy) - pv;
+  float Ju[6], Jv[6];
+  Ju[0] = fx * iz; Ju[1] = 0.0f; Ju[2] = -fxxiz * iz; Ju[3] = -fxxiz * yiz;
+  Ju[4] = fx * (1.0f + xiz * xiz); Ju[5] = -fx * yiz;
+  Jv[0] = 0.0f; Jv[1] = fy * iz; Jv[2] = -fyyiz * iz;
+  Jv[3] = -fy * (1.0f + yiz * yiz); Jv[4] = fyyiz * xiz; Jv[5] = fy * xiz;
+  // reference :1386-1452
+  const float ars = fabsf(ru) + fabsf(rv);
+  const bool hub = ars >= thr_huber;
+  const float w = hub ? thr_huber / ars : 1.0f;
+  const float wru = hub ? w * ru : ru, wrv = hub ? w * rv : rv;
+  // per-edge Hessian first, then added to the running sums (the reference forms
+  // hessian_i and appends it: same association)
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      float hv = 0.0f;
+      if (r != 1 && c != 1) hv += hub ? (w * Ju[r]) * Ju[c] : Ju[r] * Ju[c];
+      if (r != 0 && c != 0) hv += hub ? (w * Jv[r]) * Jv[c] : Jv[r] * Jv[c];
+      acc[k++] += hv;
+    }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) acc[21 + c] -= wru * Ju[c] + wrv * Jv[c];
+  acc[27] += hub ? wru * ru : rv * rv;  // reference :1432,:1450 (Q9)
+  if (ars >= thr_out) *mk = 0;          // reference :95-98 / :287-290, :321-324
+}
+
 // meta[0] = iterations executed, meta[1] = converged, meta[2] = rows logged,
 // meta[3] = success (0 = NaN)
-__global__ __launch_bounds__(kPoThreads) void k_pose_only_mono6(
-    const float *__restrict__ X3, const float *__restrict__ uv2, int n,
-    float fx, float fy, float cx, float cy, float *T12, uint8_t *mask,
+// STEREO: uvr2 = right pixels, cam_r = {fx,fy,cx,cy, Rrl(9), trl(3)} with
+// (Rrl, trl) = left_to_right^-1, maskr = right inlier mask.
+template <bool STEREO>
+__global__ __launch_bounds__(kPoThreads) void k_pose_only6(
+    const float *__restrict__ X3, const float *__restrict__ uv2,
+    const float *__restrict__ uvr2, int n, float fx, float fy, float cx, float cy,
+    const float *__restrict__ cam_r, float *T12, uint8_t *mask, uint8_t *maskr,
     float thr_huber, float thr_step, float thr_cost, float thr_out, int max_it,
     PoIter *iters, int cap, int *meta, float *debug_T12) {
   __shared__ float red[kPoWaves][kNred];
@@ -146,42 +192,33 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only_mono6(
     float acc[kNred];
 #pragma unroll
     for (int k = 0; k < kNred; ++k) acc[k] = 0.0f;
+    float cr[16];
+    if (STEREO) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) cr[k] = cam_r[k];
+    }
     for (int p = tid; p < n; p += kPoThreads) {
       const float X0 = X3[3 * p], X1 = X3[3 * p + 1], X2 = X3[3 * p + 2];
       float Lp[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         Lp[r] = (Rl[r * 3 + 0] * X0 + Rl[r * 3 + 1] * X1 + Rl[r * 3 + 2] * X2) + tl[r];
-      // reference :1350-1384
-      const float iz = 1.0f / Lp[2];
-      const float xiz = Lp[0] * iz, yiz = Lp[1] * iz;
-      const float fxxiz = fx * xiz, fyyiz = fy * yiz;
-      const float ru = (fxxiz + cx) - uv2[2 * p];
-      const float rv = (fyyiz + cy) - uv2[2 * p + 1];
-      float Ju[6], Jv[6];
-      Ju[0] = fx * iz; Ju[1] = 0.0f; Ju[2] = -fxxiz * iz; Ju[3] = -fxxiz * yiz;
-      Ju[4] = fx * (1.0f + xiz * xiz); Ju[5] = -fx * yiz;
-      Jv[0] = 0.0f; Jv[1] = fy * iz; Jv[2] = -fyyiz * iz;
-      Jv[3] = -fy * (1.0f + yiz * yiz); Jv[4] = fyyiz * xiz; Jv[5] = fy * xiz;
-      // reference :1386-1452
-      const float ars = fabsf(ru) + fabsf(rv);
-      const bool hub = ars >= thr_huber;
-      const float w = hub ? thr_huber / ars : 1.0f;
-      const float wru = hub ? w * ru : ru, wrv = hub ? w * rv : rv;
-      int k = 0;
+      po_edge(Lp, fx, fy, cx, cy, uv2[2 * p], uv2[2 * p + 1], thr_huber, thr_out, acc,
+              mask + p);
+      if (STEREO) {
+        const float pu = uvr2[2 * p], pv = uvr2[2 * p + 1];
+        if (!(pu < 0 || pv < 0)) {  // reference :298
+          float Lr[3];
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = r; c < 6; ++c) {
-          float hv = 0.0f;
-          if (r != 1 && c != 1) hv += hub ? (w * Ju[r]) * Ju[c] : Ju[r] * Ju[c];
-          if (r != 0 && c != 0) hv += hub ? (w * Jv[r]) * Jv[c] : Jv[r] * Jv[c];
-          acc[k++] += hv;
+          for (int r = 0; r < 3; ++r)
+            Lr[r] = (cr[4 + r * 3 + 0] * Lp[0] + cr[4 + r * 3 + 1] * Lp[1] +
+                     cr[4 + r * 3 + 2] * Lp[2]) +
+                    cr[13 + r];
+          po_edge(Lr, cr[0], cr[1], cr[2], cr[3], pu, pv, thr_huber, thr_out, acc,
+                  maskr + p);
+          acc[28] += 1.0f;
         }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) acc[21 + c] -= wru * Ju[c] + wrv * Jv[c];
-      acc[27] += hub ? wru * ru : rv * rv;  // reference :1432,:1450 (Q9)
-      if (ars >= thr_out) mask[p] = 0;      // reference :95-98
+      }
     }
 #pragma unroll
     for (int k = 0; k < kNred; ++k) {
@@ -249,7 +286,9 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only_mono6(
         for (int r = 0; r < 3; ++r)
           D[9 + r] = -(D[r * 3 + 0] * tn[0] + D[r * 3 + 1] * tn[1] + D[r * 3 + 2] * tn[2]);
       }
-      const float err_curr = tot[27] * (inv_n * 0.5f);
+      // mono: reference :112; stereo: :331 (count_left = n, exact in fp32 below 2^24)
+      const float err_curr = STEREO ? tot[27] / (((float)n + tot[28]) * 0.5f)
+                                    : tot[27] * (inv_n * 0.5f);
       const float delta_error = fabsf(err_curr - s_err_prev);
       const float dn = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + w0 * w0 + w1 * w1 + w2 * w2);
       meta[0] = it + 1;
@@ -294,8 +333,21 @@ int pose_only_mono6_device(const float *dX3, const float *duv2, int n, float fx,
                            float thr_cost, float thr_out, int max_it,
                            PoIter *d_iters, int cap, int *d_meta,
                            float *d_debug, hipStream_t s) {
-  hipLaunchKernelGGL(k_pose_only_mono6, dim3(1), dim3(kPoThreads), 0, s, dX3,
-                     duv2, n, fx, fy, cx, cy, dT12, dmask, thr_huber, thr_step,
+  hipLaunchKernelGGL(k_pose_only6<false>, dim3(1), dim3(kPoThreads), 0, s, dX3, duv2,
+                     (const float *)nullptr, n, fx, fy, cx, cy, (const float *)nullptr, dT12,
+                     dmask, (uint8_t *)nullptr, thr_huber, thr_step, thr_cost, thr_out, max_it,
+                     d_iters, cap, d_meta, d_debug);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int pose_only_stereo6_device(const float *dX3, const float *duvl2, const float *duvr2, int n,
+                             float fx, float fy, float cx, float cy, const float *d_cam_r16,
+                             float *dT12, uint8_t *dmask_l, uint8_t *dmask_r, float thr_huber,
+                             float thr_step, float thr_cost, float thr_out, int max_it,
+                             PoIter *d_iters, int cap, int *d_meta, float *d_debug,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(k_pose_only6<true>, dim3(1), dim3(kPoThreads), 0, s, dX3, duvl2, duvr2, n,
+                     fx, fy, cx, cy, d_cam_r16, dT12, dmask_l, dmask_r, thr_huber, thr_step,
                      thr_cost, thr_out, max_it, d_iters, cap, d_meta, d_debug);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

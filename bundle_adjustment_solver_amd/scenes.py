@@ -293,3 +293,29 @@ def hover_scene(n_pose, n_pt, n_cam, seed, n_fixed=2, visible_frac=1.0,
         obs_cam=np.concatenate(oc).astype(np.int32),
         obs_pose=np.concatenate(op).astype(np.int32),
         obs_pt=np.concatenate(oq).astype(np.int32), obs_uv=np.concatenate(uv))
+
+
+def pose_only_stereo_scene(n=10_000, seed=SEED_BASE + 6, pixel_sigma=0.0,
+                           right_missing_frac=0.2):
+    """Stereo variant of the pose-only scene (reference
+    core/pose_only_bundle_adjustment_solver.cpp:172-399 conventions): the right
+    camera sees X_r = left_to_right^-1 * X_l with left_to_right = translate(+0.12,
+    0, 0) (reference test/test_ba.cpp:88-97); a fraction of the points has no
+    right match, marked by a negative right pixel (:298)."""
+    sc = pose_only_scene(n, seed=seed, pixel_sigma=pixel_sigma)
+    rng = np.random.default_rng(seed + 1000)
+    T_lr = np.eye(4, dtype=np.float32)
+    T_lr[0, 3] = BASELINE
+    Ti = _inv(sc["T_true"].astype(np.float64)).astype(np.float32)
+    L = sc["X"] @ Ti[:3, :3].T + Ti[:3, 3]
+    Tr = _inv(T_lr.astype(np.float64)).astype(np.float32)
+    Lr = L @ Tr[:3, :3].T + Tr[:3, 3]
+    inv_z = (np.float32(1.0) / Lr[:, 2]).astype(np.float32)
+    uvr = np.stack([sc["fx"] * Lr[:, 0] * inv_z + sc["cx"],
+                    sc["fy"] * Lr[:, 1] * inv_z + sc["cy"]], axis=1).astype(np.float32)
+    if pixel_sigma > 0:
+        uvr = (uvr + rng.normal(0, pixel_sigma, uvr.shape)).astype(np.float32)
+    miss = rng.uniform(size=n) < right_missing_frac
+    uvr[miss] = -1.0
+    sc.update(uv_right=uvr, T_lr=T_lr, right_missing=miss)
+    return sc

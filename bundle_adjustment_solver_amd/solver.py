@@ -474,6 +474,44 @@ class BaProblem:
                     debug=dbg[:min(n_it.value, cap)] if want_debug else None)
 
 
+    def pose_only_stereo6(self, X3, uvl2, uvr2, intr_l, intr_r, T_lr12, T12,
+                          mask_l, mask_r, opt, cap=None, want_debug=False):
+        """reference core/pose_only_bundle_adjustment_solver.cpp:172-399."""
+        X = np.ascontiguousarray(X3, np.float32).reshape(-1, 3)
+        ul = np.ascontiguousarray(uvl2, np.float32).reshape(-1, 2)
+        ur = np.ascontiguousarray(uvr2, np.float32).reshape(-1, 2)
+        if ul.shape[0] != X.shape[0] or ur.shape[0] != X.shape[0]:
+            raise RuntimeError(  # reference :203-214
+                "In PoseOnlyBundleAdjustmentSolver::"
+                "SolveStereoPoseOnlyBundleAdjustment6Dof(), "
+                "world_position_list.size() != current_pixel_list.size()")
+        n = X.shape[0]
+        il = np.ascontiguousarray(intr_l, np.float32).reshape(4)
+        ir = np.ascontiguousarray(intr_r, np.float32).reshape(4)
+        Tlr = np.ascontiguousarray(T_lr12, np.float32).reshape(12)
+        T = np.ascontiguousarray(T12, np.float32).reshape(12).copy()
+        ml = np.ascontiguousarray(mask_l, np.uint8).copy()
+        mr = np.ascontiguousarray(mask_r, np.uint8).copy()
+        cap = cap or max(1, opt.max_num_iterations)
+        rows = (BaPoIter * cap)()
+        n_it = C.c_int(0)
+        conv = C.c_int(0)
+        dbg = np.zeros((cap, 12), np.float32) if want_debug else None
+        rc = check(self.lib.ba_pose_only_stereo6(
+            self.h, _fp(X), _fp(ul), _fp(ur), n, _fp(il), _fp(ir), _fp(Tlr),
+            _fp(T), _up(ml), _up(mr), C.byref(opt), rows, cap, C.byref(n_it),
+            C.byref(conv), _fp(dbg) if want_debug else None),
+            "ba_pose_only_stereo6")
+        nrows = n_it.value - 1 if conv.value else n_it.value
+        nrows = max(0, min(nrows, cap))
+        return dict(T12=T, mask_l=ml.astype(bool), mask_r=mr.astype(bool),
+                    n_iter=n_it.value, converged=bool(conv.value),
+                    success=(rc == 0),
+                    rows=[(rows[i].cost, rows[i].cost_change,
+                           rows[i].abs_step) for i in range(nrows)],
+                    debug=dbg[:min(n_it.value, cap)] if want_debug else None)
+
+
 class FullBundleAdjustmentSolver:
     """Mirror of reference core/full_bundle_adjustment_solver.h:127-146.
 
@@ -813,7 +851,7 @@ class FullBundleAdjustmentSolver:
 
 class PoseOnlyBundleAdjustmentSolver:
     """Mirror of reference core/pose_only_bundle_adjustment_solver.h:25-67
-    (monocular 6-DoF entry point)."""
+    (monocular and stereo 6-DoF entry points)."""
 
     def __init__(self, device=0):
         self._p = BaProblem(device)
@@ -859,6 +897,66 @@ class PoseOnlyBundleAdjustmentSolver:
             mask_inlier[...] = res["mask"]
         if res["success"]:
             reference_to_current_pose[...] = _T12_to_44(res["T12"])[0]
+        if summary is not None:
+            for cost, dchg, step in res["rows"]:
+                info = OptimizationInfo()
+                info.cost = cost
+                info.cost_change = abs(dchg)
+                info.average_reprojection_error = cost
+                info.abs_step = step
+                info.abs_gradient = 0
+                info.damping_term = -1
+                info.iter_time = 0.0
+                info.iteration_status = IterationStatus.UPDATE
+                summary.optimization_info_list_.append(info)
+            summary.convergence_status_ = res["converged"]
+            summary.total_time_in_millisecond_ = \
+                (time.perf_counter() - t0) * 1e3
+        return res["success"]
+
+    def Solve_Stereo_6Dof(self, reference_position_list, matched_left_pixel_list,
+                          matched_right_pixel_list, fx_left, fy_left, cx_left,
+                          cy_left, fx_right, fy_right, cx_right, cy_right,
+                          left_to_right_pose, reference_to_current_left_pose,
+                          mask_inlier_left, mask_inlier_right, options,
+                          summary=None):
+        """reference core/pose_only_bundle_adjustment_solver.cpp:172-399.
+        Poses are 4x4 arrays (the left pose is updated in place), the masks
+        lists/arrays resized to n (True) and updated in place; a right pixel
+        with a negative coordinate means "not matched in the right image"."""
+        t0 = time.perf_counter()
+        X = np.asarray(reference_position_list, np.float32).reshape(-1, 3)
+        ul = np.asarray(matched_left_pixel_list, np.float32).reshape(-1, 2)
+        ur = np.asarray(matched_right_pixel_list, np.float32).reshape(-1, 2)
+        n = X.shape[0]
+        if summary is not None:
+            summary.max_iteration_ = options.iteration_handle.max_num_iterations
+            summary.threshold_cost_change_ = \
+                options.convergence_handle.threshold_cost_change
+            summary.threshold_step_size_ = \
+                options.convergence_handle.threshold_step_size
+            summary.convergence_status_ = True
+
+        def fit(mask):
+            m = np.ones(n, np.uint8)
+            k = min(len(mask), n)
+            m[:k] = np.asarray(mask[:k], np.uint8)
+            return m
+
+        to12 = lambda T: _T44_to_12(np.asarray(T, np.float64)).astype(np.float32)
+        res = self._p.pose_only_stereo6(
+            X, ul, ur, [fx_left, fy_left, cx_left, cy_left],
+            [fx_right, fy_right, cx_right, cy_right], to12(left_to_right_pose),
+            to12(reference_to_current_left_pose), fit(mask_inlier_left),
+            fit(mask_inlier_right), options.to_c(), want_debug=True)
+        self.debug_poses_ = [_T12_to_44(d)[0] for d in res["debug"]]
+        for mask, key in ((mask_inlier_left, "mask_l"), (mask_inlier_right, "mask_r")):
+            if isinstance(mask, list):
+                mask[:] = [bool(v) for v in res[key]]
+            else:
+                mask[...] = res[key]
+        if res["success"]:
+            reference_to_current_left_pose[...] = _T12_to_44(res["T12"])[0]
         if summary is not None:
             for cost, dchg, step in res["rows"]:
                 info = OptimizationInfo()

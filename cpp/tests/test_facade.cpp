@@ -217,6 +217,31 @@ int main() {
                 ps.GetOptimizationInfoList().size(), po.GetDebugPoses().size(), err);
     EXPECT(err < 1e-3f, "pose-only did not recover the true pose");
     EXPECT(mask.size() == 10000, "mask size");
+    // stereo entry point: right camera 0.12 m to the right, every third point unmatched
+    Eigen::Isometry3f T_lr = Eigen::Isometry3f::Identity();
+    T_lr.translation() = Eigen::Vector3f(0.12f, 0.f, 0.f);
+    const Eigen::Isometry3f T_rl = T_lr.inverse();
+    std::vector<Eigen::Vector2f> pxr;
+    for (int k = 0; k < 10000; ++k) {
+      const Eigen::Vector3f lr = T_rl * (Ti * Xw[k]);
+      if (k % 3 == 0) pxr.push_back(Eigen::Vector2f(-1.f, -1.f));
+      else pxr.push_back(Eigen::Vector2f(338.f * lr(0) / lr(2) + 320.f, 338.f * lr(1) / lr(2) + 240.f));
+    }
+    Eigen::Isometry3f pose_s = Eigen::Isometry3f::Identity();
+    std::vector<bool> ml, mr;
+    Summary ss;
+    EXPECT(po.Solve_Stereo_6Dof(Xw, px, pxr, 338.f, 338.f, 320.f, 240.f, 338.f, 338.f, 320.f, 240.f, T_lr, pose_s,
+                                ml, mr, popt, &ss),
+           "stereo pose-only solve");
+    float errs = 0.f;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) errs = std::fmax(errs, std::fabs(pose_s.linear()(r, c) - T_true.linear()(r, c)));
+      errs = std::fmax(errs, std::fabs(pose_s.translation()(r) - T_true.translation()(r)));
+    }
+    std::printf("stereo pose-only: %zu summary rows, max |T - T_true| = %.2e\n",
+                ss.GetOptimizationInfoList().size(), errs);
+    EXPECT(errs < 1e-3f, "stereo pose-only did not recover the true pose");
+    EXPECT(ml.size() == 10000 && mr.size() == 10000, "stereo mask sizes");
   }
   std::printf(g_fail ? "C++ FACADE TEST FAILED (%d)\n" : "C++ FACADE TEST PASSED\n", g_fail);
   return g_fail ? 1 : 0;

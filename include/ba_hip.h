@@ -205,6 +205,19 @@ int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
                        int cap, int *n_iter, int *converged,
                        float *debug_T12);
 
+/* ---- pose-only, stereo 6-DoF (fp32) ------------------------------------- */
+/* Solve_Stereo_6Dof, reference
+ * core/pose_only_bundle_adjustment_solver.cpp:172-399.  intr_*4 = fx,fy,cx,cy;
+ * T_lr12 = left_to_right_pose; T12 in/out = reference_to_current_left_pose;
+ * a right pixel with a negative coordinate means "no right observation"
+ * (:298); mask_l / mask_r are n bytes each, in/out (sticky false). */
+int ba_pose_only_stereo6(ba_handle *h, const float *X3, const float *uvl2,
+                         const float *uvr2, int n, const float *intr_l4,
+                         const float *intr_r4, const float *T_lr12, float *T12,
+                         uint8_t *mask_l, uint8_t *mask_r, const ba_options *opt,
+                         ba_po_iter *iters, int cap, int *n_iter, int *converged,
+                         float *debug_T12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -866,12 +866,19 @@ void ba_oracle_ldlt_solve(int n, const double *A_rowmajor, int nrhs,
 // :1338-1348 (warp), :1350-1384 (Jacobian), :1386-1452 (gradient / Hessian),
 // :1147-1200 (upper-triangle append / mirror), :1280-1316 (se3 exp).
 // ---------------------------------------------------------------------------
-int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
-                              float fx, float fy, float cx, float cy,
-                              float *T12, uint8_t *mask,
-                              const ba_oracle_options *opt,
-                              ba_oracle_po_iter *iters, int cap, int *n_iter,
-                              int *converged, float *debug_T12) {
+// Shared Gauss-Newton loop of the pose-only solvers.  uvr == nullptr: monocular
+// (reference :8-170).  Otherwise stereo (reference :172-399): the right camera
+// sees X_r = (left_to_right)^-1 * X_l (Rrl, trl), contributes only where its
+// pixel is non-negative (:298), has its own mask, and the error is normalised by
+// (count_left + count_right) * 0.5f (:331).
+static int pose_only_core(const float *X3, const float *uv2, const float *uvr,
+                          int n, float fx, float fy, float cx, float cy,
+                          float fxr, float fyr, float cxr, float cyr,
+                          const float *Rrl, const float *trl, float *T12,
+                          uint8_t *mask, uint8_t *maskr,
+                          const ba_oracle_options *opt,
+                          ba_oracle_po_iter *iters, int cap, int *n_iter,
+                          int *converged, float *debug_T12) {
   const float thr_huber = opt->threshold_huber_loss;
   const float thr_step = opt->threshold_step_size;
   const float thr_cost = opt->threshold_cost_change;
@@ -896,6 +903,7 @@ int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
     for (int k = 0; k < 36; ++k) H[k] = 0.0f;
     for (int k = 0; k < 6; ++k) g[k] = 0.0f;
     float err_curr = 0.0f;
+    size_t count_right = 0;
     for (int p = 0; p < n; ++p) {
       const float *Xp = X3 + 3 * p;
       float L[3];
@@ -903,11 +911,14 @@ int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
         L[r] = (R[r * 3 + 0] * Xp[0] + R[r * 3 + 1] * Xp[1] +
                 R[r * 3 + 2] * Xp[2]) +
                t[r];
+      // one camera's terms (reference :1350-1452)
+      auto edge = [&](const float *L, float fx, float fy, float cx, float cy,
+                      float pu, float pv, uint8_t *mk) {
       const float iz = 1.0f / L[2];
       const float xiz = L[0] * iz, yiz = L[1] * iz;
       const float fxxiz = fx * xiz, fyyiz = fy * yiz;
-      const float ru = (fxxiz + cx) - uv2[2 * p + 0];
-      const float rv = (fyyiz + cy) - uv2[2 * p + 1];
+      const float ru = (fxxiz + cx) - pu;
+      const float rv = (fyyiz + cy) - pv;
       float Ju[6], Jv[6];
       Ju[0] = fx * iz;
       Ju[1] = 0.0f;
@@ -956,7 +967,18 @@ int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
       for (int r = 0; r < 6; ++r)
         for (int c = r; c < 6; ++c) H[r * 6 + c] += Hi[r * 6 + c];
       err_curr += error_i;
-      if (ars >= thr_out) mask[p] = 0;
+      if (ars >= thr_out) mk[p] = 0;
+      };
+      edge(L, fx, fy, cx, cy, uv2[2 * p + 0], uv2[2 * p + 1], mask);
+      if (uvr && !(uvr[2 * p + 0] < 0 || uvr[2 * p + 1] < 0)) {  // :298
+        ++count_right;
+        float Lr[3];
+        for (int r = 0; r < 3; ++r)
+          Lr[r] = (Rrl[r * 3 + 0] * L[0] + Rrl[r * 3 + 1] * L[1] +
+                   Rrl[r * 3 + 2] * L[2]) +
+                  trl[r];
+        edge(Lr, fxr, fyr, cxr, cyr, uvr[2 * p + 0], uvr[2 * p + 1], maskr);
+      }
     }
     for (int r = 0; r < 6; ++r)
       for (int c = r + 1; c < 6; ++c) H[c * 6 + r] = H[r * 6 + c];
@@ -1050,7 +1072,10 @@ int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
         D[9 + r] = -(D[r * 3 + 0] * t[0] + D[r * 3 + 1] * t[1] +
                      D[r * 3 + 2] * t[2]);
     }
-    err_curr *= (inv_n * 0.5f);
+    if (uvr)
+      err_curr /= ((size_t)n + count_right) * 0.5f;  // :331
+    else
+      err_curr *= (inv_n * 0.5f);
     const float delta_error = std::fabs(err_curr - err_prev);
     float dn = 0.0f;
     for (int k = 0; k < 6; ++k) dn += d[k] * d[k];
@@ -1080,6 +1105,39 @@ int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
     T12[9 + r] = -(T12[r * 3 + 0] * t[0] + T12[r * 3 + 1] * t[1] +
                    T12[r * 3 + 2] * t[2]);
   return 1;
+}
+
+
+int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
+                              float fx, float fy, float cx, float cy,
+                              float *T12, uint8_t *mask,
+                              const ba_oracle_options *opt,
+                              ba_oracle_po_iter *iters, int cap, int *n_iter,
+                              int *converged, float *debug_T12) {
+  return pose_only_core(X3, uv2, nullptr, n, fx, fy, cx, cy, 0, 0, 0, 0, nullptr,
+                        nullptr, T12, mask, nullptr, opt, iters, cap, n_iter,
+                        converged, debug_T12);
+}
+
+// reference core/pose_only_bundle_adjustment_solver.cpp:172-399
+int ba_oracle_pose_only_stereo6(const float *X3, const float *uvl2,
+                                const float *uvr2, int n, const float *intr_l4,
+                                const float *intr_r4, const float *T_lr12,
+                                float *T12, uint8_t *mask_l, uint8_t *mask_r,
+                                const ba_oracle_options *opt,
+                                ba_oracle_po_iter *iters, int cap, int *n_iter,
+                                int *converged, float *debug_T12) {
+  // pose_right_to_left = left_to_right_pose.inverse()  (:226)
+  float Rrl[9], trl[3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Rrl[r * 3 + c] = T_lr12[c * 3 + r];
+  for (int r = 0; r < 3; ++r)
+    trl[r] = -(Rrl[r * 3 + 0] * T_lr12[9] + Rrl[r * 3 + 1] * T_lr12[10] +
+               Rrl[r * 3 + 2] * T_lr12[11]);
+  return pose_only_core(X3, uvl2, uvr2, n, intr_l4[0], intr_l4[1], intr_l4[2],
+                        intr_l4[3], intr_r4[0], intr_r4[1], intr_r4[2], intr_r4[3],
+                        Rrl, trl, T12, mask_l, mask_r, opt, iters, cap, n_iter,
+                        converged, debug_T12);
 }
 
 }  // extern "C"

@@ -137,6 +137,18 @@ int ba_oracle_pose_only_mono6(const float *X3, const float *uv2, int n,
                               ba_oracle_po_iter *iters, int cap, int *n_iter,
                               int *converged, float *debug_T12 /* cap*12 or NULL */);
 
+/* --- pose-only, stereo 6-DoF (fp32), reference
+ * core/pose_only_bundle_adjustment_solver.cpp:172-399 --- */
+/* intr_*4 = fx,fy,cx,cy; T_lr12 = left_to_right_pose; a right pixel with a
+ * negative coordinate marks "no right observation" (:298). */
+int ba_oracle_pose_only_stereo6(const float *X3, const float *uvl2,
+                                const float *uvr2, int n, const float *intr_l4,
+                                const float *intr_r4, const float *T_lr12,
+                                float *T12, uint8_t *mask_l, uint8_t *mask_r,
+                                const ba_oracle_options *opt,
+                                ba_oracle_po_iter *iters, int cap, int *n_iter,
+                                int *converged, float *debug_T12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,11 @@ def load():
     L.ba_oracle_set_x.argtypes = [C.c_void_p, _D]
     L.ba_oracle_get_pairs.argtypes = [C.c_void_p, _I, _I, _D]
     L.ba_oracle_ldlt_solve.argtypes = [C.c_int, _D, C.c_int, _D, _D]
+    L.ba_oracle_pose_only_stereo6.restype = C.c_int
+    L.ba_oracle_pose_only_stereo6.argtypes = [
+        _F, _F, _F, C.c_int, _F, _F, _F, _F, _U, _U,
+        C.POINTER(OracleOptions), C.POINTER(OraclePoIter), C.c_int,
+        C.POINTER(C.c_int), C.POINTER(C.c_int), _F]
     L.ba_oracle_pose_only_mono6.restype = C.c_int
     L.ba_oracle_pose_only_mono6.argtypes = [
         _F, _F, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _F, _U,
@@ -282,6 +287,41 @@ def pose_only_mono6(X3, uv2, fx, fy, cx, cy, T44, mask, opt, want_debug=False):
     nrows = max(0, min(nrows, cap))
     return dict(T12=T12, mask=m.astype(bool), n_iter=n_it.value,
                 converged=bool(conv.value), success=bool(ok),
+                rows=[(rows[i].cost, rows[i].cost_change, rows[i].abs_step)
+                      for i in range(nrows)],
+                debug=dbg[:min(n_it.value, cap)])
+
+
+def pose_only_stereo6(X3, uvl2, uvr2, intr_l, intr_r, T_lr44, T44, mask_l,
+                      mask_r, opt):
+    """reference core/pose_only_bundle_adjustment_solver.cpp:172-399."""
+    L = load()
+    X = np.ascontiguousarray(X3, np.float32).reshape(-1, 3)
+    ul = np.ascontiguousarray(uvl2, np.float32).reshape(-1, 2)
+    ur = np.ascontiguousarray(uvr2, np.float32).reshape(-1, 2)
+    n = X.shape[0]
+    to12 = lambda T: np.concatenate(
+        [np.asarray(T, np.float32)[:3, :3].reshape(9),
+         np.asarray(T, np.float32)[:3, 3]]).astype(np.float32)
+    T12, Tlr = to12(T44), to12(T_lr44)
+    il = np.ascontiguousarray(intr_l, np.float32)
+    ir = np.ascontiguousarray(intr_r, np.float32)
+    ml = np.ascontiguousarray(mask_l, np.uint8).copy()
+    mr = np.ascontiguousarray(mask_r, np.uint8).copy()
+    cap = max(1, opt.max_num_iterations)
+    rows = (OraclePoIter * cap)()
+    n_it, conv = C.c_int(0), C.c_int(0)
+    dbg = np.zeros((cap, 12), np.float32)
+    ok = L.ba_oracle_pose_only_stereo6(
+        X.ctypes.data_as(_F), ul.ctypes.data_as(_F), ur.ctypes.data_as(_F), n,
+        il.ctypes.data_as(_F), ir.ctypes.data_as(_F), Tlr.ctypes.data_as(_F),
+        T12.ctypes.data_as(_F), ml.ctypes.data_as(_U), mr.ctypes.data_as(_U),
+        C.byref(opt), rows, cap, C.byref(n_it), C.byref(conv),
+        dbg.ctypes.data_as(_F))
+    nrows = n_it.value - 1 if conv.value else n_it.value
+    nrows = max(0, min(nrows, cap))
+    return dict(T12=T12, mask_l=ml.astype(bool), mask_r=mr.astype(bool),
+                n_iter=n_it.value, converged=bool(conv.value), success=bool(ok),
                 rows=[(rows[i].cost, rows[i].cost_change, rows[i].abs_step)
                       for i in range(nrows)],
                 debug=dbg[:min(n_it.value, cap)])

@@ -57,7 +57,26 @@ def pose_only():
         json.dump(gold, f, indent=0)
 
 
+def pose_only_stereo():
+    sc = scenes.pose_only_stereo_scene(1000, seed=43, right_missing_frac=0.25)
+    opt = O.make_options(max_iter=100, thr_step=1e-6, thr_cost=1e-6,
+                         huber=1.0, outlier=2.5)
+    intr = [sc["fx"], sc["fy"], sc["cx"], sc["cy"]]
+    ones = np.ones(1000, np.uint8)
+    res = O.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
+                              sc["T_lr"], sc["T_init"], ones, ones, opt)
+    gold = dict(n=1000, seed=43, right_missing_frac=0.25, n_iter=res["n_iter"],
+                converged=res["converged"],
+                rows=[list(map(float, r)) for r in res["rows"]],
+                T12=res["T12"].astype(float).tolist(),
+                n_inlier_left=int(res["mask_l"].sum()),
+                n_inlier_right=int(res["mask_r"].sum()))
+    with open(os.path.join(HERE, "pose_only_stereo_golden.json"), "w") as f:
+        json.dump(gold, f, indent=0)
+
+
 if __name__ == "__main__":
     full_ba()
     pose_only()
+    pose_only_stereo()
     print("golden fixtures written")

@@ -85,3 +85,68 @@ def test_recovers_true_pose_and_golden(built):
     with pytest.raises(RuntimeError):
         s.Solve_Monocular_6Dof(list(sc["X"]), list(sc["uv"][:-1]), 1, 1, 0, 0,
                                pose, mask, opt)
+
+
+# ---- stereo 6-DoF (reference :172-399) --------------------
+@pytest.mark.parametrize("n,seed,sigma,miss", [(10_000, 2025, 0.0, 0.2),
+                                               (3000, 9, 0.5, 0.5),
+                                               (2000, 3, 0.0, 1.0)])
+def test_stereo_matches_oracle(n, seed, sigma, miss, built):
+    sc = scenes.pose_only_stereo_scene(n, seed=seed, pixel_sigma=sigma,
+                                       right_missing_frac=miss)
+    intr = [sc["fx"], sc["fy"], sc["cx"], sc["cy"]]
+    to12 = lambda T: np.concatenate([T[:3, :3].reshape(9), T[:3, 3]])
+    g = BaProblem(0)
+    res = g.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
+                              to12(sc["T_lr"]), to12(sc["T_init"]),
+                              np.ones(n, np.uint8), np.ones(n, np.uint8),
+                              po_options(BaOptions), want_debug=True)
+    ref = O.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
+                              sc["T_lr"], sc["T_init"], np.ones(n, np.uint8),
+                              np.ones(n, np.uint8), po_options())
+    assert res["success"] and ref["success"]
+    assert res["converged"] == ref["converged"]
+    assert abs(res["n_iter"] - ref["n_iter"]) <= 1
+    assert np.abs(res["T12"] - ref["T12"]).max() < 1e-4
+    k = min(len(res["rows"]), len(ref["rows"]), 6)
+    for a, b in zip(res["rows"][:k], ref["rows"][:k]):
+        assert abs(a[0] - b[0]) <= 1e-3 * max(abs(b[0]), 1e-3)
+        assert abs(a[2] - b[2]) <= 1e-3 * max(abs(b[2]), 1e-3)
+    assert (res["mask_l"] != ref["mask_l"]).sum() <= max(2, n // 1000)
+    assert (res["mask_r"] != ref["mask_r"]).sum() <= max(2, n // 1000)
+    # points without a right match never lose their right inlier flag
+    assert res["mask_r"][sc["right_missing"]].all()
+    assert np.abs(res["debug"][-1] - res["T12"]).max() < 1e-6
+    if sigma == 0.0:
+        Tt = to12(sc["T_true"])
+        assert np.abs(res["T12"] - Tt).max() < 1e-3
+
+
+def test_stereo_facade_and_mono_limit(built):
+    """Solve_Stereo_6Dof through the facade; with no right match at all it
+    must land on the monocular solution."""
+    sc = scenes.pose_only_stereo_scene(4000, seed=12, right_missing_frac=1.0)
+    opt = Options()
+    opt.iteration_handle.max_num_iterations = 100
+    opt.convergence_handle.threshold_cost_change = 1e-6
+    opt.convergence_handle.threshold_step_size = 1e-6
+    opt.outlier_handle.threshold_huber_loss = 1.0
+    opt.outlier_handle.threshold_outlier_rejection = 2.5
+    s = PoseOnlyBundleAdjustmentSolver()
+    pose_s = sc["T_init"].astype(np.float64).copy()
+    ml, mr = [], []
+    summ = Summary()
+    assert s.Solve_Stereo_6Dof(list(sc["X"]), list(sc["uv"]), list(sc["uv_right"]),
+                               sc["fx"], sc["fy"], sc["cx"], sc["cy"],
+                               sc["fx"], sc["fy"], sc["cx"], sc["cy"],
+                               sc["T_lr"], pose_s, ml, mr, opt, summ)
+    assert len(ml) == len(mr) == 4000 and all(mr)
+    assert len(s.GetDebugPoses()) >= 1
+    pose_m = sc["T_init"].astype(np.float64).copy()
+    assert s.Solve_Monocular_6Dof(list(sc["X"]), list(sc["uv"]), sc["fx"], sc["fy"],
+                                  sc["cx"], sc["cy"], pose_m, [], opt, None)
+    assert np.abs(pose_s - pose_m).max() < 1e-5
+    with pytest.raises(RuntimeError):
+        s.Solve_Stereo_6Dof(list(sc["X"]), list(sc["uv"])[:-1], list(sc["uv_right"]),
+                            sc["fx"], sc["fy"], sc["cx"], sc["cy"], sc["fx"], sc["fy"],
+                            sc["cx"], sc["cy"], sc["T_lr"], pose_s, ml, mr, opt, None)

@@ -276,3 +276,48 @@ def test_pose_only_oracle_recovers_pose(built):
     assert np.abs(T[9:] - sc["T_true"][:3, 3]).max() < 1e-3
     # Q9: no Summary row on the converging iteration
     assert len(res["rows"]) == res["n_iter"] - 1
+
+
+def test_stereo_pose_only_oracle_recovers_pose_and_has_mono_limit():
+    """reference core/pose_only_bundle_adjustment_solver.cpp:172-399 restated:
+    converges to the true pose on noise-free data; with no right match at all it
+    is the monocular solver (the right camera contributes nothing, :298)."""
+    from bundle_adjustment_solver_amd import scenes
+    sc = scenes.pose_only_stereo_scene(3000, seed=5, right_missing_frac=0.3)
+    intr = [sc["fx"], sc["fy"], sc["cx"], sc["cy"]]
+    opt = O.make_options(max_iter=100, thr_step=1e-6, thr_cost=1e-6, huber=1.0,
+                         outlier=2.5)
+    ones = np.ones(3000, np.uint8)
+    r = O.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
+                            sc["T_lr"], sc["T_init"], ones, ones, opt)
+    Tt = np.concatenate([sc["T_true"][:3, :3].reshape(9), sc["T_true"][:3, 3]])
+    assert r["success"] and r["converged"] and np.abs(r["T12"] - Tt).max() < 1e-5
+    assert r["mask_r"][sc["right_missing"]].all()
+    sc2 = scenes.pose_only_stereo_scene(3000, seed=5, right_missing_frac=1.0)
+    r2 = O.pose_only_stereo6(sc2["X"], sc2["uv"], sc2["uv_right"], intr, intr,
+                             sc2["T_lr"], sc2["T_init"], ones, ones, opt)
+    m = O.pose_only_mono6(sc2["X"], sc2["uv"], sc2["fx"], sc2["fy"], sc2["cx"],
+                          sc2["cy"], sc2["T_init"], ones, opt)
+    assert np.abs(r2["T12"] - m["T12"]).max() < 1e-6 and r2["n_iter"] == m["n_iter"]
+
+
+def test_stereo_pose_only_golden_vector():
+    """Committed regression vector of the stereo pose-only oracle."""
+    import json
+    import os
+    from bundle_adjustment_solver_amd import scenes
+    with open(os.path.join(os.path.dirname(__file__), "golden",
+                           "pose_only_stereo_golden.json")) as f:
+        gold = json.load(f)
+    sc = scenes.pose_only_stereo_scene(gold["n"], seed=gold["seed"],
+                                       right_missing_frac=gold["right_missing_frac"])
+    intr = [sc["fx"], sc["fy"], sc["cx"], sc["cy"]]
+    ones = np.ones(gold["n"], np.uint8)
+    opt = O.make_options(max_iter=100, thr_step=1e-6, thr_cost=1e-6, huber=1.0,
+                         outlier=2.5)
+    r = O.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
+                            sc["T_lr"], sc["T_init"], ones, ones, opt)
+    assert r["n_iter"] == gold["n_iter"] and r["converged"] == gold["converged"]
+    assert np.abs(r["T12"] - np.array(gold["T12"])).max() < 1e-6
+    assert int(r["mask_l"].sum()) == gold["n_inlier_left"]
+    assert int(r["mask_r"].sum()) == gold["n_inlier_right"]
