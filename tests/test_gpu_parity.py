@@ -399,3 +399,31 @@ def test_all_poses_fixed_and_no_observations(built):
     assert [r.iteration_status for r in rows] == [r.iteration_status for r in orows]
     assert np.array_equal(g.get_points()[0], pr["pt_X"])
     assert np.array_equal(g.get_poses(), pr["pose_T"])
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_structures(seed, built):
+    """Randomised visibility graphs (dense to very sparse), pose / landmark
+    counts, camera counts, fixed poses and fixed landmarks: the reduced system,
+    three LM iterations and the final parameters must match the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n_pose = int(rng.integers(3, 70))
+    n_pt = int(rng.integers(20, 400))
+    n_cam = int(rng.integers(1, 4))
+    frac = float(rng.choice([0.05, 0.15, 0.4, 0.9]))
+    sc = scenes.hover_scene(n_pose, n_pt, n_cam, seed=2000 + seed,
+                            n_fixed=int(rng.integers(1, max(2, n_pose // 3))),
+                            visible_frac=frac)
+    sc["pt_fixed"][rng.uniform(size=n_pt) < 0.1] = True
+    if sc["obs_pt"].size == 0:
+        pytest.skip("empty draw")
+    _compare_solve(scenes.scaled_problem(sc), iters=3, tol_par=1e-5)
+
+
+@pytest.mark.parametrize("window", [15, 16, 20])
+def test_wide_windows_around_the_slot_limit(window, built):
+    """A landmark seen by d poses touches d(d+1)/2 blocks of S: d = 15 (120
+    blocks) still fits the 128 register-resident slots of a super-run, d = 16
+    (136) and d = 20 (210) go through the global triple list."""
+    sc = scenes.synthetic_ba_scene(48, 700, window, False, seed=30 + window)
+    _compare_solve(scenes.scaled_problem(sc), iters=4, tol_par=1e-5)
