@@ -6,11 +6,13 @@ The numerical path lives in libba_hip.so (include/ba_hip.h); importing this
 package does not touch the GPU, creating a solver does.
 """
 from .solver import (BaProblem, Camera, FullBundleAdjustmentSolver,  # noqa
+                     FullBundleAdjustmentSolverRefactor,
                      IterationStatus, OptimizationInfo, Options,
                      PoseOnlyBundleAdjustmentSolver, SolverType, Summary)
 from . import scenes  # noqa
 
 __all__ = ["BaProblem", "Camera", "FullBundleAdjustmentSolver",
+           "FullBundleAdjustmentSolverRefactor",
            "IterationStatus", "OptimizationInfo", "Options",
            "PoseOnlyBundleAdjustmentSolver", "SolverType", "Summary",
            "scenes"]

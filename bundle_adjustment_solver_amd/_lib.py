@@ -21,6 +21,7 @@ class BaOptions(C.Structure):
         ("initial_lambda", C.c_float),
         ("decrease_ratio_lambda", C.c_float),
         ("increase_ratio_lambda", C.c_float),
+        ("gauss_newton", C.c_int),
     ]
 
 

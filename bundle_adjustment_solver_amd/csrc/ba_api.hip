@@ -626,6 +626,7 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
   c.dec_ratio = (double)opt->decrease_ratio_lambda;
   c.inc_ratio = (double)opt->increase_ratio_lambda;
   c.max_iter = opt->max_num_iterations;
+  c.gn = opt->gauss_newton ? 1 : 0;
   c.iter = 0;
   c.converged = 0;
   c.done = (opt->max_num_iterations <= 0) ? 1 : 0;

@@ -27,7 +27,8 @@ struct DevCtrl {
   int iter;       // iterations completed
   int converged;
   int max_iter;
-  int pad_[3];
+  int gn;         // 1: plain Gauss-Newton (always accept, lambda fixed)
+  int pad_[2];
 };
 
 struct DevIterRec {  // layout-identical to ba_iter_info

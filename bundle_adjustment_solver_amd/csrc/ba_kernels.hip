@@ -1462,20 +1462,28 @@ __device__ void control_step(const DevProblem &d) {
   const double current_cost = d.scal[0];
   const double model = -d.scal[1];
   const double previous_cost = c->prev_cost;
-  const double rho = (current_cost - previous_cost) * 100.0 / model;
+  double rho = (current_cost - previous_cost) * 100.0 / model;
   int status;
-  if (rho > 0.25) {
-    status = 0;
-    c->cur ^= 1;  // the trial buffer becomes the accepted one
-  } else {
-    status = 2;   // keep the reserved parameters (reference :943)
-  }
   double lambda = c->lambda;
-  if (rho > 0.5) {
-    lambda = fmax(1e-10, lambda * c->dec_ratio);
-    status = 1;
-  } else if (rho <= 0.25) {
-    lambda = fmin(100.0, lambda * c->inc_ratio);
+  if (c->gn) {
+    // plain Gauss-Newton of the refactored solver (reference
+    // core/full_bundle_adjustment_solver_refactor.cpp:976-982)
+    status = 0;
+    rho = 0.0;
+    c->cur ^= 1;
+  } else {
+    if (rho > 0.25) {
+      status = 0;
+      c->cur ^= 1;  // the trial buffer becomes the accepted one
+    } else {
+      status = 2;   // keep the reserved parameters (reference :943)
+    }
+    if (rho > 0.5) {
+      lambda = fmax(1e-10, lambda * c->dec_ratio);
+      status = 1;
+    } else if (rho <= 0.25) {
+      lambda = fmin(100.0, lambda * c->inc_ratio);
+    }
   }
   c->lambda = lambda;
   const double n_obs = (double)d.n_obs_global;
@@ -1498,7 +1506,7 @@ __device__ void control_step(const DevProblem &d) {
     I.iteration_status = status;
     I.pad_ = 0;
     I.rho = rho;
-    I.model_change = model;
+    I.model_change = c->gn ? 0.0 : model;
     I.trial_cost = current_cost;
     if (status == 2) {  // reference :995-1000
       I.cost = previous_cost;

@@ -791,6 +791,11 @@ class FullBundleAdjustmentSolver:
               (2 * self.num_total_observations_))
         return ""
 
+    def _use_gauss_newton(self, options):
+        """FullBundleAdjustmentSolver::Solve ignores options.solver_type and is
+        always Levenberg-Marquardt."""
+        return False
+
     def Solve(self, options, summary=None):             # reference :630-1044
         t0 = time.perf_counter()
         if summary is not None:
@@ -804,7 +809,9 @@ class FullBundleAdjustmentSolver:
         if self.verbose:
             self.GetSolverStatistics()
         p = self._problem
-        rows, converged = p.solve(options.to_c())
+        c_opt = options.to_c()
+        c_opt.gauss_newton = 1 if self._use_gauss_newton(options) else 0
+        rows, converged = p.solve(c_opt)
         # write back through the user's objects (reference :1011-1022)
         T_jw = p.get_poses()
         T44 = _T12_to_44(T_jw)
@@ -973,3 +980,34 @@ class PoseOnlyBundleAdjustmentSolver:
             summary.total_time_in_millisecond_ = \
                 (time.perf_counter() - t0) * 1e3
         return res["success"]
+
+
+class FullBundleAdjustmentSolverRefactor(FullBundleAdjustmentSolver):
+    """Mirror of reference core/full_bundle_adjustment_solver_refactor.h:
+    117-136: the same device path behind the refactored names, plus the
+    solver_type switch of its Solve (reference ..._refactor.cpp:944-982):
+    LEVENBERG_MARQUARDT, or GAUSS_NEWTON = every step accepted with lambda fixed
+    at initial_lambda (the default of Options)."""
+
+    def RegisterCamera(self, camera_id, camera):
+        return self.AddCamera(camera_id, camera)
+
+    def RegisterWorldToBodyPose(self, original_pose):
+        return self.AddPose(original_pose)
+
+    def RegisterWorldPoint(self, original_point):
+        return self.AddPoint(original_point)
+
+    def _use_gauss_newton(self, options):
+        if options.solver_type == SolverType.LEVENBERG_MARQUARDT:
+            return False
+        if options.solver_type == SolverType.GAUSS_NEWTON:
+            return True
+        raise RuntimeError("FullBundleAdjustmentSolverRefactor::Solve: "
+                           "solver_type must be GAUSS_NEWTON or "
+                           "LEVENBERG_MARQUARDT")
+
+    def SolveByGradientDescent(self, options, summary=None):
+        raise NotImplementedError(
+            "SolveByGradientDescent (reference ..._refactor.cpp:1073-1370) is "
+            "not on the MI355X hot path")

@@ -80,6 +80,10 @@ class FullBundleAdjustmentSolver {
   // GPU selection / console chatter (not in the reference)
   void SetDevice(int device_id) { device_id_ = device_id; }
   void SetVerbose(bool on) { verbose_ = on; }
+  // Plain Gauss-Newton instead of Levenberg-Marquardt.  FullBundleAdjustmentSolver
+  // itself never sets it (its Solve ignores options.solver_type, reference
+  // :630-1044); FullBundleAdjustmentSolverRefactor does.
+  void SetGaussNewton(bool on) { gauss_newton_ = on; }
 
  private:
   struct Observation {
@@ -92,6 +96,7 @@ class FullBundleAdjustmentSolver {
   _BA_Numeric inverse_scaler_{100.0};
   bool is_parameter_finalized_{false};
   bool verbose_{true};
+  bool gauss_newton_{false};
   int device_id_{0};
   ba_handle *handle_{nullptr};
 

@@ -230,6 +230,7 @@ bool FullBundleAdjustmentSolver::Solve(Options options, Summary *summary) {  // 
   o.initial_lambda = options.trust_region_handle.initial_lambda;
   o.decrease_ratio_lambda = options.trust_region_handle.decrease_ratio_lambda;
   o.increase_ratio_lambda = options.trust_region_handle.increase_ratio_lambda;
+  o.gauss_newton = gauss_newton_ ? 1 : 0;
   std::vector<ba_iter_info> rows(static_cast<size_t>(std::max(1, o.max_num_iterations)));
   int n_iter = 0, converged = 0;
   Check(ba_solve(handle_, &o, rows.data(), static_cast<int>(rows.size()), &n_iter, &converged), "ba_solve");

@@ -61,6 +61,7 @@ bool PoseOnlyBundleAdjustmentSolver::Solve_Monocular_6Dof(
   o.initial_lambda = options.trust_region_handle.initial_lambda;
   o.decrease_ratio_lambda = options.trust_region_handle.decrease_ratio_lambda;
   o.increase_ratio_lambda = options.trust_region_handle.increase_ratio_lambda;
+  o.gauss_newton = 0;
   const int cap = o.max_num_iterations > 0 ? o.max_num_iterations : 1;
   std::vector<ba_po_iter> rows(cap);
   std::vector<float> dbg(static_cast<size_t>(cap) * 12);
@@ -168,6 +169,7 @@ bool PoseOnlyBundleAdjustmentSolver::Solve_Stereo_6Dof(
   o.initial_lambda = options.trust_region_handle.initial_lambda;
   o.decrease_ratio_lambda = options.trust_region_handle.decrease_ratio_lambda;
   o.increase_ratio_lambda = options.trust_region_handle.increase_ratio_lambda;
+  o.gauss_newton = 0;
   const int cap = o.max_num_iterations > 0 ? o.max_num_iterations : 1;
   std::vector<ba_po_iter> rows(cap);
   std::vector<float> dbg(static_cast<size_t>(cap) * 12);

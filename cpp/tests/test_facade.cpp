@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "core/full_bundle_adjustment_solver.h"
+#include "core/full_bundle_adjustment_solver_refactor.h"
 #include "core/pose_only_bundle_adjustment_solver.h"
 #include "eigen3/Eigen/Dense"
 #include "eigen3/Eigen/Geometry"
@@ -181,6 +182,67 @@ int main() {
   std::printf("max |pose - oracle| = %.3e   max |point - oracle| = %.3e (user units)\n", max_dp, max_dx);
   EXPECT(max_dp < 1e-6 && max_dx < 1e-6, "final parameters differ from the oracle");
   ba_oracle_destroy(orc);
+
+  // ---------------- refactored API, Gauss-Newton mode (reference test_ba_refactor.cpp:236-299) ----------------
+  {
+    std::unordered_map<int, Pose> poses2;
+    std::unordered_map<int, Point> points2;
+    for (int j = 0; j < num_total_poses; ++j) poses2[j] = true_poses[j];
+    for (int j = num_fixed_poses; j < num_total_poses; ++j) poses2[j].translation().x() += 0.01 * ((j % 7) - 3);
+    for (size_t i = 0; i < true_points.size(); ++i) {
+      points2[(int)i] = true_points[i];
+      points2[(int)i].z() += 0.02 * ((int)(i % 5) - 2);
+    }
+    // oracle on the same registered problem
+    std::vector<double> pT(12 * num_total_poses), pX(3 * true_points.size());
+    for (int j = 0; j < num_total_poses; ++j) {
+      Pose T = poses2[j].inverse();
+      T.translation() = T.translation() * s;
+      Pack12(T, &pT[12 * j]);
+    }
+    for (size_t i = 0; i < true_points.size(); ++i)
+      for (int a = 0; a < 3; ++a) pX[3 * i + a] = points2[(int)i](a) * s;
+    ba_oracle *o2 = ba_oracle_create(2, cam_intr.data(), cam_T.data(), num_total_poses, pT.data(), pose_fixed.data(),
+                                     (int)true_points.size(), pX.data(), pt_fixed.data(), (int64_t)oc.size(),
+                                     oc.data(), op.data(), oq.data(), uv.data());
+    FullBundleAdjustmentSolverRefactor rf;
+    rf.SetVerbose(false);
+    for (int c = 0; c < 2; ++c) {
+      OptimizerCamera oc2;
+      oc2.fx = cameras[c].fx; oc2.fy = cameras[c].fy; oc2.cx = cameras[c].cx; oc2.cy = cameras[c].cy;
+      oc2.camera_to_body_pose = cameras[c].pose_this_to_cam0;
+      rf.RegisterCamera(c, oc2);
+    }
+    for (int j = 0; j < num_total_poses; ++j) rf.RegisterWorldToBodyPose(&poses2[j]);
+    for (size_t i = 0; i < true_points.size(); ++i) rf.RegisterWorldPoint(&points2[(int)i]);
+    for (int j = 0; j < num_fixed_poses; ++j) rf.MakePoseFixed(&poses2[j]);
+    for (const Obs &ob : obs) rf.AddObservation(ob.cam, &poses2[ob.pose], &points2[ob.point], ob.px);
+    Options gopt;
+    gopt.solver_type = SolverType::GAUSS_NEWTON;
+    gopt.iteration_handle.max_num_iterations = 6;
+    gopt.convergence_handle.threshold_cost_change = 0.f;
+    gopt.convergence_handle.threshold_step_size = 0.f;
+    gopt.trust_region_handle.initial_lambda = 1e-3f;
+    Summary gs;
+    EXPECT(rf.Solve(gopt, &gs), "refactor Solve");
+    ba_oracle_options go{0.f, 0.f, 1.0f, 2.0f, 6, 1e-3f, 0.33f, 3.0f, 1};
+    std::vector<ba_oracle_iter> grows(6);
+    int gconv = 0;
+    const int gn = ba_oracle_solve(o2, &go, grows.data(), 6, &gconv);
+    const auto &gr = gs.GetOptimizationInfoList();
+    EXPECT((int)gr.size() == gn && gn == 6, "GN iterations %zu vs %d", gr.size(), gn);
+    for (size_t k = 0; k < gr.size() && (int)k < gn; ++k) {
+      EXPECT((int)gr[k].iteration_status == 0 && grows[k].iteration_status == 0, "GN status at %zu", k);
+      EXPECT(std::fabs(gr[k].cost - grows[k].cost) <= 1e-7 * std::fabs(grows[k].cost) + 1e-12, "GN cost at %zu", k);
+    }
+    std::printf("refactor API, Gauss-Newton: cost %.4e -> %.4e in %d iterations (oracle %.4e)\n", gr.front().cost,
+                gr.back().cost, gn, grows[gn - 1].cost);
+    bool threw2 = false;
+    gopt.solver_type = SolverType::UNDEFINED;
+    try { rf.Solve(gopt, nullptr); } catch (const std::runtime_error &) { threw2 = true; }
+    EXPECT(threw2, "undefined solver_type must throw");
+    ba_oracle_destroy(o2);
+  }
 
   // ---------------- pose-only facade ----------------
   {

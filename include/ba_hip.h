@@ -41,6 +41,12 @@ typedef struct {
   float initial_lambda;              /* trust_region_handle */
   float decrease_ratio_lambda;
   float increase_ratio_lambda;
+  /* 1 = plain Gauss-Newton of FullBundleAdjustmentSolverRefactor (reference
+   * core/full_bundle_adjustment_solver_refactor.cpp:976-982: every step
+   * accepted, lambda fixed at initial_lambda); 0 = Levenberg-Marquardt, the
+   * only mode of FullBundleAdjustmentSolver::Solve (its solver_type is
+   * ignored, reference :630-1044). */
+  int gauss_newton;
 } ba_options;
 
 /* One row per LM iteration: OptimizationInfo (reference

@@ -732,23 +732,28 @@ int ba_oracle_solve(ba_oracle *o, const ba_oracle_options *opt,
     ba_oracle_backup(o);
     ba_oracle_update(o);
     const double current_cost = ba_oracle_cost(o);
-    const double model = ba_oracle_model_change(o);
-    // :930  inverse_scaler_ = 100
-    const double rho = (current_cost - previous_cost) * 100.0 / model;
-    int status;
-    if (rho > 0.25) {
-      status = 0;
+    double model = 0.0, rho = 0.0;
+    int status = 0;
+    if (opt->gauss_newton) {
+      // refactor :976-982: update, evaluate the cost, status UPDATE
     } else {
-      ba_oracle_revert(o);
-      status = 2;
-    }
-    if (rho > 0.5) {
-      lambda = std::max(1e-10,
-                        (double)(lambda * opt->decrease_ratio_lambda));
-      status = 1;
-    } else if (rho <= 0.25) {
-      lambda = std::min(100.0,
-                        (double)(lambda * opt->increase_ratio_lambda));
+      model = ba_oracle_model_change(o);
+      // :930  inverse_scaler_ = 100
+      rho = (current_cost - previous_cost) * 100.0 / model;
+      if (rho > 0.25) {
+        status = 0;
+      } else {
+        ba_oracle_revert(o);
+        status = 2;
+      }
+      if (rho > 0.5) {
+        lambda = std::max(1e-10,
+                          (double)(lambda * opt->decrease_ratio_lambda));
+        status = 1;
+      } else if (rho <= 0.25) {
+        lambda = std::min(100.0,
+                          (double)(lambda * opt->increase_ratio_lambda));
+      }
     }
     const double average_error = current_cost / (double)o->n_obs;
     const double cost_change = std::fabs(current_cost - previous_cost);

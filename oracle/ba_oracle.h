@@ -39,6 +39,10 @@ typedef struct {
   float initial_lambda;
   float decrease_ratio_lambda;
   float increase_ratio_lambda;
+  /* 1: plain Gauss-Newton of the refactored solver (reference
+   * core/full_bundle_adjustment_solver_refactor.cpp:976-982): every step is
+   * accepted, lambda stays at initial_lambda.  0: Levenberg-Marquardt. */
+  int gauss_newton;
 } ba_oracle_options;
 
 /* One row per LM iteration; mirrors OptimizationInfo

@@ -21,7 +21,8 @@ class OracleOptions(C.Structure):
                 ("max_num_iterations", C.c_int),
                 ("initial_lambda", C.c_float),
                 ("decrease_ratio_lambda", C.c_float),
-                ("increase_ratio_lambda", C.c_float)]
+                ("increase_ratio_lambda", C.c_float),
+                ("gauss_newton", C.c_int)]
 
 
 class OracleIter(C.Structure):
@@ -106,8 +107,10 @@ def _dp(a):
 
 
 def make_options(max_iter=50, thr_step=1e-5, thr_cost=1e-5, huber=1.0,
-                 outlier=2.0, lambda0=100.0, dec=0.33, inc=3.0, cls=None):
+                 outlier=2.0, lambda0=100.0, dec=0.33, inc=3.0, cls=None,
+                 gauss_newton=False):
     o = (cls or OracleOptions)()
+    o.gauss_newton = 1 if gauss_newton else 0
     o.threshold_step_size = thr_step
     o.threshold_cost_change = thr_cost
     o.threshold_huber_loss = huber

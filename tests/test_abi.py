@@ -32,7 +32,7 @@ def test_header_symbols_all_exported_and_bound(built):
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.BaOptions) == 32
+    assert C.sizeof(_lib.BaOptions) == 36   # 7 floats + max_num_iterations + gauss_newton
     assert C.sizeof(_lib.BaIterInfo) == 8 * 7 + 8 + 8 * 3
     assert C.sizeof(_lib.BaPoIter) == 12
 

@@ -427,3 +427,53 @@ def test_wide_windows_around_the_slot_limit(window, built):
     (136) and d = 20 (210) go through the global triple list."""
     sc = scenes.synthetic_ba_scene(48, 700, window, False, seed=30 + window)
     _compare_solve(scenes.scaled_problem(sc), iters=4, tol_par=1e-5)
+
+
+def test_gauss_newton_mode_of_the_refactored_solver(built):
+    """ba_options.gauss_newton (reference ..._refactor.cpp:976-982): every step
+    is accepted with lambda fixed at initial_lambda; the Python
+    FullBundleAdjustmentSolverRefactor facade selects it from
+    options.solver_type."""
+    from bundle_adjustment_solver_amd import (FullBundleAdjustmentSolverRefactor,
+                                              Options, SolverType, Summary)
+    sc = scenes.synthetic_ba_scene(16, 400, 5, True, seed=77, pose_noise=0.02,
+                                   point_noise=0.05)
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    kw = dict(max_iter=6, thr_step=0, thr_cost=0, lambda0=1e-3, gauss_newton=True)
+    rows, _ = g.solve(O.make_options(cls=BaOptions, **kw))
+    orows, _ = o.solve(O.make_options(**kw))
+    assert len(rows) == len(orows) == 6
+    for a, b in zip(rows, orows):
+        assert a.iteration_status == b.iteration_status == 0
+        assert a.damping_term == b.damping_term == pytest.approx(1e-3)
+        assert relerr(a.cost, b.cost) < 1e-7
+    assert relerr(g.get_poses(), o.get_poses()) < 1e-6
+    assert relerr(g.get_points()[0], o.get_points()) < 1e-6
+    assert rows[-1].cost < 0.5 * rows[0].cost       # GN makes progress on this scene
+    # facade: GAUSS_NEWTON (default of Options) vs LEVENBERG_MARQUARDT
+    from bundle_adjustment_solver_amd import Camera
+    outs = {}
+    for st in (SolverType.GAUSS_NEWTON, SolverType.LEVENBERG_MARQUARDT):
+        s = FullBundleAdjustmentSolverRefactor()
+        for c in range(sc["intr"].shape[0]):
+            s.RegisterCamera(c, Camera(*sc["intr"][c], pose_this_to_cam0=sc["T_cj"][c]))
+        poses = [sc["T_wc_init"][k].copy() for k in range(16)]
+        pts = [sc["X_init"][k].copy() for k in range(400)]
+        for T in poses:
+            s.RegisterWorldToBodyPose(T)
+        for X in pts:
+            s.RegisterWorldPoint(X)
+        for k in range(5):
+            s.MakePoseFixed(poses[k])
+        for c, j, i, uv in zip(sc["obs_cam"], sc["obs_pose"], sc["obs_pt"], sc["obs_uv"]):
+            s.AddObservation(int(c), poses[j], pts[i], uv)
+        opt = Options()
+        opt.solver_type = st
+        opt.iteration_handle.max_num_iterations = 5
+        opt.trust_region_handle.initial_lambda = 1e-3
+        summ = Summary()
+        assert s.Solve(opt, summ)
+        outs[st] = [i.iteration_status for i in summ.optimization_info_list_]
+    assert all(int(v) == 0 for v in outs[SolverType.GAUSS_NEWTON])
+    assert any(int(v) == 1 for v in outs[SolverType.LEVENBERG_MARQUARDT])
