@@ -129,7 +129,7 @@ struct DevProblem {
   int n_zt;
 };
 
-constexpr int kCostGrid = 1024;
+constexpr int kCostGrid = 1792;  // 7 waves/SIMD resident on 256 CUs
 constexpr int kLmGrid = 1024;
 constexpr int kPoseGrid = 16;
 constexpr int kSlotStride = 42;  // 6x6 block of B Cinv B^T + 6 of B Cinv b

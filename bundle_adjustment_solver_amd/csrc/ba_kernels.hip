@@ -325,8 +325,9 @@ __device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
       uvn = d.obs_uv[s2_];                                                      \
     }                                                                           \
     ObsGeom g_;                                                                 \
-    double cam_[16];                                                            \
-    load_cam<LDSCAM>(d, cams_s, ccam, cam_);                                    \
+    /* camera through a pointer (LDS table or global): fewer live registers */  \
+    const double *cam_ = LDSCAM ? (const double *)(cams_s + ccam * 16)          \
+                                : (const double *)(d.cams + (size_t)ccam * 16); \
     project(cam_, TC, XC[0], XC[1], XC[2], cuv.x, cuv.y, g_);                   \
     acc += sqrt(g_.r0 * g_.r0 + g_.r1 * g_.r1);                                 \
     ccam = ncam_;                                                               \
