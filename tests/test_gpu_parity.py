@@ -477,3 +477,44 @@ def test_gauss_newton_mode_of_the_refactored_solver(built):
         outs[st] = [i.iteration_status for i in summ.optimization_info_list_]
     assert all(int(v) == 0 for v in outs[SolverType.GAUSS_NEWTON])
     assert any(int(v) == 1 for v in outs[SolverType.LEVENBERG_MARQUARDT])
+
+
+def test_full_size_configs_properties(built):
+    """BASELINE.json sizes, through size-independent properties (the oracle
+    needs ~20 s per iteration at C4): C2 converges towards the ground truth of
+    its noise-free scene; C4 is bitwise reproducible run to run, accepted steps
+    never increase the cost, and one handle re-solved from the same start
+    repeats its trajectory."""
+    opts = dict(thr_step=0, thr_cost=0, cls=BaOptions)
+    # ---- C2: 200 poses / 50 k landmarks / 500 k observations (mono) ----
+    sc = scenes.config_scene("C2")
+    pr = scenes.scaled_problem(sc)
+    g = make_gpu(pr)
+    rows, _ = g.solve(O.make_options(max_iter=40, **opts))
+    X0 = pr["pt_X"]
+    Xt = sc["X_true"] * 0.01
+    e0 = np.linalg.norm(X0 - Xt, axis=1)
+    e1 = np.linalg.norm(g.get_points()[0] - Xt, axis=1)
+    assert np.median(e1) < 0.1 * np.median(e0)
+    assert rows[-1].cost < 1e-2 * rows[0].cost
+    for r in rows:
+        if r.iteration_status != 2:       # accepted step: rho > 0.25 > 0
+            assert r.rho > 0.25
+    del g
+    # ---- C4: 1000 poses / 500 k landmarks / 5 M observations (stereo) ----
+    sc = scenes.config_scene("C4")
+    pr = scenes.scaled_problem(sc)
+    logs = []
+    for _ in range(2):
+        g = make_gpu(pr)
+        rows, _ = g.solve(O.make_options(max_iter=6, **opts))
+        logs.append([(r.cost, r.damping_term, r.iteration_status, r.trial_cost)
+                     for r in rows])
+        P, X = g.get_poses().copy(), g.get_points()[0].copy()
+        if len(logs) == 1:
+            P0, X0 = P, X
+        del g
+    assert logs[0] == logs[1]                          # bitwise, run to run
+    assert np.array_equal(P0, P) and np.array_equal(X0, X)
+    costs = [c for c, _, st, _ in logs[0] if st != 2]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))
