@@ -518,3 +518,36 @@ def test_full_size_configs_properties(built):
     assert np.array_equal(P0, P) and np.array_equal(X0, X)
     costs = [c for c, _, st, _ in logs[0] if st != 2]
     assert all(b <= a for a, b in zip(costs, costs[1:]))
+
+
+def test_handles_release_their_device_memory(built):
+    """create -> finalize -> solve -> destroy cycles must not leak device
+    memory (handles own every buffer, incl. the side stream, events, graph)."""
+    torch = pytest.importorskip("torch")   # same HIP runtime as libba_hip.so (see _lib)
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    sc = scenes.synthetic_ba_scene(30, 4000, 5, True, seed=3)
+    pr = scenes.scaled_problem(sc)
+    opt = O.make_options(max_iter=4, thr_step=0, thr_cost=0, cls=BaOptions)
+    def cycle():
+        g = make_gpu(pr)
+        g.solve(opt)
+        g.pose_only_mono6(np.random.rand(100, 3).astype(np.float32) + [0, 0, 2],
+                          np.random.rand(100, 2).astype(np.float32) * 100, 300, 300,
+                          320, 240,
+                          np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32),
+                          np.ones(100, np.uint8), opt)
+        g.close()
+
+    # one-time runtime reservations (code objects, the kernel scratch pool of the
+    # HIP queues: ~100 MB once, then constant) happen in the first cycles
+    for _ in range(10):
+        cycle()
+    before = free_bytes()
+    for _ in range(25):
+        cycle()
+    after = free_bytes()
+    assert before - after < 16 << 20, (before, after)
