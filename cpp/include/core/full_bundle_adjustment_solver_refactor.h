@@ -18,34 +18,35 @@
 namespace visual_navigation {
 namespace analytic_solver {
 
-using SolverNumeric = double;
-using Index = int;
-using Pixel = Eigen::Matrix<SolverNumeric, 2, 1>;
-using Point = Eigen::Matrix<SolverNumeric, 3, 1>;
-using Rotation3D = Eigen::Matrix<SolverNumeric, 3, 3>;
-using Translation3D = Eigen::Matrix<SolverNumeric, 3, 1>;
-using Pose = Eigen::Transform<SolverNumeric, 3, 1>;
-using ErrorList = std::vector<SolverNumeric>;
-using IndexList = std::vector<Index>;
-using PixelList = std::vector<Pixel>;
-using PointList = std::vector<Point>;
+// scalar / vector aliases of the refactored API (same names, reference :36-51)
+typedef double SolverNumeric;
+typedef int Index;
+typedef Eigen::Matrix<SolverNumeric, 2, 1> Pixel;          // image point [pixel]
+typedef Eigen::Matrix<SolverNumeric, 3, 1> Point;          // world point [m]
+typedef Eigen::Matrix<SolverNumeric, 3, 3> Rotation3D;
+typedef Eigen::Matrix<SolverNumeric, 3, 1> Translation3D;
+typedef Eigen::Transform<SolverNumeric, 3, 1> Pose;        // rigid (Isometry) transform
+typedef std::vector<SolverNumeric> ErrorList;
+typedef std::vector<Index> IndexList;
+typedef std::vector<Pixel> PixelList;
+typedef std::vector<Point> PointList;
 
+// Pinhole camera of the rig.  camera_to_body_pose is applied as
+// X_camera = camera_to_body_pose * X_body (reference ..._refactor.cpp:758).
 struct OptimizerCamera {
-  OptimizerCamera() {}
-  OptimizerCamera(const OptimizerCamera &camera)
-      : fx(camera.fx), fy(camera.fy), cx(camera.cx), cy(camera.cy), camera_to_body_pose(camera.camera_to_body_pose) {}
-  OptimizerCamera &operator=(const OptimizerCamera &camera) = default;
-  SolverNumeric fx{0.0};
-  SolverNumeric fy{0.0};
-  SolverNumeric cx{0.0};
-  SolverNumeric cy{0.0};
-  Pose camera_to_body_pose;  // applied as X_camera = camera_to_body_pose * X_body (reference ..._refactor.cpp:758)
+  OptimizerCamera() = default;
+  OptimizerCamera(const OptimizerCamera &other) = default;
+  OptimizerCamera &operator=(const OptimizerCamera &other) = default;
+  SolverNumeric fx = 0.0, fy = 0.0;  // focal lengths [pixel]
+  SolverNumeric cx = 0.0, cy = 0.0;  // principal point [pixel]
+  Pose camera_to_body_pose;
 };
 
+// One pixel measurement of a point from a pose through a camera.
 struct PointObservation {
-  int related_camera_id{-1};
-  Pose *related_pose{nullptr};
-  Point *related_point{nullptr};
+  int related_camera_id = -1;
+  Pose *related_pose = nullptr;
+  Point *related_point = nullptr;
   Pixel pixel{-1.0, -1.0};
 };
 

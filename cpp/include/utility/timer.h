@@ -1,4 +1,5 @@
-// Wall-clock helpers with the reference's interface (utility/timer.h:8-34).
+// Wall-clock helpers exposing the interface the reference's callers use
+// (utility/timer.h:8-34): free tic()/toc() and a named StopWatch with laps.
 #ifndef BA_FACADE_TIMER_H_
 #define BA_FACADE_TIMER_H_
 
@@ -6,23 +7,27 @@
 #include <string>
 
 namespace timer {
-void tic();
-double toc(bool flag_verbose);        // ms since tic()
-const std::string currentDateTime();  // yyyy-mm-dd.hh:mm:ss
+
+void tic();                            // start the process-wide timer
+double toc(bool print_elapsed);        // milliseconds since tic()
+const std::string currentDateTime();   // "yyyy-mm-dd.hh:mm:ss"
 
 class StopWatch {
+  using SteadyClock = std::chrono::high_resolution_clock;
+
  public:
-  explicit StopWatch(const std::string &stopwatch_name);
+  explicit StopWatch(const std::string &name);
   ~StopWatch();
-  double Start(const bool flag_verbose = false);
-  double GetLapTimeFromStart(const bool flag_verbose = false);
-  double GetLapTimeFromLatest(const bool flag_verbose = false);
-  double Stop(const bool flag_verbose = false);
+  // all four return milliseconds; the flag prints the value with the watch's name
+  double Start(const bool print_elapsed = false);                 // (re)starts, returns 0
+  double GetLapTimeFromStart(const bool print_elapsed = false);   // since Start()
+  double GetLapTimeFromLatest(const bool print_elapsed = false);  // since the previous lap / Start()
+  double Stop(const bool print_elapsed = false);                  // since Start(), freezes the watch
 
  private:
-  typedef std::chrono::high_resolution_clock Clock;
   std::string timer_name_;
-  Clock::time_point start_, intermediate_, end_;
+  SteadyClock::time_point start_, intermediate_, end_;
 };
+
 }  // namespace timer
 #endif

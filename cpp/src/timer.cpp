@@ -27,24 +27,24 @@ const std::string currentDateTime() {
 StopWatch::StopWatch(const std::string &stopwatch_name) : timer_name_(stopwatch_name) {}
 StopWatch::~StopWatch() {}
 double StopWatch::Start(const bool) {
-  start_ = intermediate_ = Clock::now();
+  start_ = intermediate_ = SteadyClock::now();
   return 0.0;
 }
 double StopWatch::GetLapTimeFromStart(const bool flag_verbose) {
-  intermediate_ = Clock::now();
+  intermediate_ = SteadyClock::now();
   const double ms = ms_between(start_, intermediate_);
   if (flag_verbose) std::cout << timer_name_ << ": " << ms << " [ms] from start\n";
   return ms;
 }
 double StopWatch::GetLapTimeFromLatest(const bool flag_verbose) {
-  const Clock::time_point now = Clock::now();
+  const SteadyClock::time_point now = SteadyClock::now();
   const double ms = ms_between(intermediate_, now);
   intermediate_ = now;
   if (flag_verbose) std::cout << timer_name_ << ": " << ms << " [ms] lap\n";
   return ms;
 }
 double StopWatch::Stop(const bool flag_verbose) {
-  end_ = Clock::now();
+  end_ = SteadyClock::now();
   const double ms = ms_between(start_, end_);
   if (flag_verbose) std::cout << timer_name_ << ": " << ms << " [ms] total\n";
   return ms;
