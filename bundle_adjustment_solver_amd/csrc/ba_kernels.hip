@@ -1404,7 +1404,6 @@ __device__ void control_step(const DevProblem &d);
 constexpr int kScalBlock = 1024;
 __global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode) {
   if (d.ctrl->done) return;
-  __shared__ double sm[kScalBlock / 64];
   double c = 0.0, e = 0.0, n = 0.0, pe = 0.0, pn = 0.0;
 #pragma unroll 1
   for (int k = threadIdx.x; k < kCostGrid; k += kScalBlock) c += d.cost_part[k];
@@ -1429,11 +1428,31 @@ __global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode) 
       pn = d.pose_part[2 + 2 * threadIdx.x + 1];
     }
   }
-  const double tc = block_sum(c, sm);
-  const double te = block_sum(e, sm);
-  const double tn = block_sum(n, sm);
-  const double tpe = block_sum(pe, sm);
-  const double tpn = block_sum(pn, sm);
+  // five sums, one barrier pair: wave totals -> LDS -> thread 0 adds the 16 waves in order
+  __shared__ double sm5[5][kScalBlock / 64];
+  {
+    const double w0 = wave_sum(c), w1 = wave_sum(e), w2 = wave_sum(n), w3 = wave_sum(pe),
+                 w4 = wave_sum(pn);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+      sm5[0][wv] = w0;
+      sm5[1][wv] = w1;
+      sm5[2][wv] = w2;
+      sm5[3][wv] = w3;
+      sm5[4][wv] = w4;
+    }
+  }
+  __syncthreads();
+  double tc = 0.0, te = 0.0, tn = 0.0, tpe = 0.0, tpn = 0.0;
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < kScalBlock / 64; ++w) {
+      tc += sm5[0][w];
+      te += sm5[1][w];
+      tn += sm5[2][w];
+      tpe += sm5[3][w];
+      tpn += sm5[4][w];
+    }
+  }
   if (threadIdx.x == 0) {
     if (mode >= 1) {
       d.pose_part[0] = tpe;
