@@ -546,6 +546,7 @@ int ba_finalize(ba_handle *h) {
         h->upload(&dd.tgt_I, sc.tgt_I) || h->upload(&dd.tgt_J, sc.tgt_J) ||
         h->upload(&dd.tgt_src_ptr, sc.tgt_src_ptr) || h->upload(&dd.src_t, sc.src_t) ||
         h->upload(&dd.tgt_desc, sc.tgt_desc) || h->upload(&dd.back_desc, sc.back_desc) ||
+        h->upload(&dd.row_desc, sc.row_desc) ||
         h->dalloc(&dd.xc, (size_t)d.npad))
       return -1;
     if (sc.fused_ok &&
@@ -964,7 +965,7 @@ const char *ba_kernel_name(int id) {
   static const char *names[ba::K_COUNT] = {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
       "k_schur_lds", "k_schur_partial", "k_schur_final", "k_scatter",
-      "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_backsub_update",
+      "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_chol_diag_trsm", "k_backsub_update",
       "k_pose_update", "k_scalars", "k_control"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
 }
@@ -1034,7 +1035,7 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   if (up(&dd.row_ptr, sc.row_ptr) || up(&dd.rows, sc.rows) || up(&dd.item_t, sc.item_t) ||
       up(&dd.item_I, sc.item_I) || up(&dd.tgt_I, sc.tgt_I) || up(&dd.tgt_J, sc.tgt_J) ||
       up(&dd.tgt_src_ptr, sc.tgt_src_ptr) || up(&dd.src_t, sc.src_t) || up(&dd.col_x, col_x) ||
-      up(&dd.tgt_desc, sc.tgt_desc) || up(&dd.back_desc, sc.back_desc))
+      up(&dd.tgt_desc, sc.tgt_desc) || up(&dd.back_desc, sc.back_desc) || up(&dd.row_desc, sc.row_desc))
     return -1;
   if (sc.fused_ok) {
     if (up(&dd.f_desc, sc.f_desc) || up(&dd.f_pend, sc.f_pend)) return -1;
@@ -1061,7 +1062,7 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   for (void *p : {(void *)dL, (void *)dD, (void *)dx, (void *)dd.xc, (void *)dd.row_ptr,
                   (void *)dd.rows, (void *)dd.item_t, (void *)dd.item_I, (void *)dd.tgt_I,
                   (void *)dd.tgt_J, (void *)dd.tgt_src_ptr, (void *)dd.src_t, (void *)dd.col_x,
-                  (void *)dd.tgt_desc, (void *)dd.back_desc, (void *)dd.f_desc,
+                  (void *)dd.tgt_desc, (void *)dd.back_desc, (void *)dd.row_desc, (void *)dd.f_desc,
                   (void *)dd.f_pend, (void *)dd.cbuf})
     (void)hipFree(p);
   HIP_TRY(hipGetLastError());

@@ -155,11 +155,16 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
                 dd.f_desc, dd.rows, dd.f_pend, dd.cbuf, Ldiag, done);                       \
       continue;                                                                             \
     }                                                                                       \
-    BA_LAUNCH(K_CHOL_DIAG, NS::k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag, done); \
     const int it0 = sc.item_ptr[l], ni = sc.item_ptr[l + 1] - it0;                          \
-    if (ni > 0)                                                                             \
-      BA_LAUNCH(K_CHOL_TRSM, NS::k_chol_trsm, dim3(ni), dim3(NS::NP * 64), s, L, ld,        \
-                row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);                         \
+    if (split) {                                                                            \
+      BA_LAUNCH(K_CHOL_DIAG, NS::k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag, done); \
+      if (ni > 0)                                                                           \
+        BA_LAUNCH(K_CHOL_TRSM, NS::k_chol_trsm, dim3(ni), dim3(NS::NP * 64), s, L, ld,      \
+                  row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);                       \
+    } else {                                                                                \
+      BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_diag_trsm, dim3(nt), dim3(256), s, L, ld,      \
+                npad, t0, dd.row_desc, dd.rows, Ldiag, done);                               \
+    }                                                                                       \
     const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0;                            \
     if (ng > 0)                                                                             \
       BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(ng), dim3(256), s, L, ld, tg0,       \
@@ -181,6 +186,14 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   // lists, which their single consumer then gathers serially.
   const char *fz = getenv("BA_DENSE_FUSED");
   const bool fused = sc.fused_ok && dd.f_desc && fz && fz[0] == '1';
+  // BA_DENSE_SPLIT=1: separate diagonal and TRSM launches (the TRSM then spreads
+  // over one workgroup per row tile: better for dense patterns with many row
+  // tiles per column); default: the tile's workgroup also solves its row tiles
+  const char *sp = getenv("BA_DENSE_SPLIT");
+  // (all row tiles of a column must fit the prefetched passes: 4 passes x
+  //  (4 waves / (nb/16)) tiles)
+  const bool split = (sp && sp[0] == '1') || !dd.row_desc || sc.max_rows > 4 * (4 / (sc.nb / 16));
+  (void)row_limit;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

@@ -195,6 +195,15 @@ void build_dense_schedule(int ncb, const std::vector<uint8_t> &adj_in,
       s.n_contrib = next;
     }
   }
+  s.row_desc.assign(16 * (size_t)n, -1);
+  for (int p = 0; p < n; ++p) {
+    int *q = &s.row_desc[16 * (size_t)p];
+    q[0] = s.row_ptr[p + 1] - s.row_ptr[p];
+    q[1] = s.row_ptr[p];
+    s.max_rows = std::max(s.max_rows, q[0]);
+    for (int k = 2; k < 8; ++k) q[k] = 0;
+    for (int a = 0; a < 8 && a < q[0]; ++a) q[8 + a] = s.rows[q[1] + a];
+  }
   s.back_desc.assign(8 * (size_t)n, -1);
   for (int p = 0; p < n; ++p) {
     int *q = &s.back_desc[8 * (size_t)p];

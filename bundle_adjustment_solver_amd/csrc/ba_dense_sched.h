@@ -51,6 +51,9 @@ struct DenseSchedule {
   //   tgt_desc[8 tg ..] = { I, J, nsrc, src_begin, first four sources (-1 pad) }
   //   back_desc[8 p ..] = { nrow (without the rhs block), row_begin, first six rows }
   std::vector<int> tgt_desc, back_desc;
+  //   row_desc[16 p ..] = { nrow (incl. the rhs block), row_begin, 0.., first eight row tiles at [8..15] }
+  std::vector<int> row_desc;
+  int max_rows = 0;  // most row tiles (incl. the rhs block) below any tile
   // FUSED level schedule (one launch per level, see k_chol_level): every source
   // tile writes its outer products P_a P_c^T as separate CONTRIBUTION tiles
   // instead of updating the targets in place; a tile subtracts its pending

@@ -141,7 +141,7 @@ constexpr int kSlotStride = 42;  // 6x6 block of B Cinv B^T + 6 of B Cinv b
 enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
   K_SCHUR_LDS, K_SCHUR_PARTIAL, K_SCHUR_FINAL, K_SCATTER,
-  K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_BACKSUB_UPDATE,
+  K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_CHOL_DIAG_TRSM, K_BACKSUB_UPDATE,
   K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_COUNT
 };
 struct KernelTimer {
@@ -202,6 +202,7 @@ struct DenseDev {
   int *tgt_I = nullptr, *tgt_J = nullptr;        // update targets
   int *tgt_src_ptr = nullptr, *src_t = nullptr;  // their source panels
   int *tgt_desc = nullptr, *back_desc = nullptr; // 8-int inline records
+  int *row_desc = nullptr;                       // 16-int records: row tiles of a position
   // fused level path (DenseSchedule::fused_ok)
   int *f_desc = nullptr, *f_pend = nullptr;
   double *cbuf = nullptr;  // n_contrib contribution tiles (NB x NB, column-major)
