@@ -46,7 +46,7 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
-PMC_SUMMARY = {"C4": "profiles/r01_c4_pmc_fetch_write_v8.txt"}
+PMC_SUMMARY = {"C4": "profiles/r01_c4_pmc_fetch_write_v9.txt"}
 
 
 def pmc_traffic(kernel, config):
@@ -235,7 +235,7 @@ def main():
             }
             tot = {k: v[0] / n_prof for k, v in km.items() if v[1]}
             dense = sum(tot.get(k, 0.0) for k in
-                        ("k_chol_diag", "k_chol_trsm", "k_chol_update",
+                        ("k_chol_diag", "k_chol_trsm", "k_chol_diag_trsm", "k_chol_update",
                          "k_chol_back", "k_chol_level"))
             dom = max(kbytes, key=lambda k: tot.get(k, 0.0))
             dom_ms = tot[dom] / km[dom][1] * n_prof   # average launch duration
