@@ -551,3 +551,24 @@ def test_handles_release_their_device_memory(built):
         cycle()
     after = free_bytes()
     assert before - after < 16 << 20, (before, after)
+
+
+def test_config_c2_and_c3_first_iterations_match_oracle(built):
+    """BASELINE.json configs C2 (mono 200 / 50 k / 500 k) and C3 (stereo 500 /
+    200 k / 2 M) directly against the oracle: two LM iterations each (the
+    oracle's dense LDLT makes a C3 iteration take a few seconds)."""
+    for name in ("C2", "C3"):
+        sc = scenes.config_scene(name)
+        pr = scenes.scaled_problem(sc)
+        g, o = make_gpu(pr), O.Oracle(pr)
+        rows, _ = g.solve(O.make_options(max_iter=2, thr_step=0, thr_cost=0, cls=BaOptions))
+        orows, _ = o.solve(O.make_options(max_iter=2, thr_step=0, thr_cost=0))
+        assert len(rows) == len(orows) == 2
+        for a, b in zip(rows, orows):
+            assert a.iteration_status == b.iteration_status
+            assert relerr(a.trial_cost, b.trial_cost) < 1e-8
+            assert relerr(a.damping_term, b.damping_term) < 1e-12
+        # north-star tolerance: 1e-4 relative on poses / points
+        assert relerr(g.get_poses(), o.get_poses()) < RTOL_FINAL
+        assert relerr(g.get_points()[0], o.get_points()) < RTOL_FINAL
+        del g, o
