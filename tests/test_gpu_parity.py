@@ -572,3 +572,19 @@ def test_config_c2_and_c3_first_iterations_match_oracle(built):
         assert relerr(g.get_poses(), o.get_poses()) < RTOL_FINAL
         assert relerr(g.get_points()[0], o.get_points()) < RTOL_FINAL
         del g, o
+
+
+def test_config_c4_first_iteration_matches_oracle(built):
+    """The headline configuration (stereo 1000 / 500 k / 5 M) against the oracle:
+    one LM iteration (the oracle needs about 20 s for it, nearly all of it in the
+    reference-style dense LDLT of the 5970 x 5970 reduced system)."""
+    sc = scenes.config_scene("C4")
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    rows, _ = g.solve(O.make_options(max_iter=1, thr_step=0, thr_cost=0, cls=BaOptions))
+    orows, _ = o.solve(O.make_options(max_iter=1, thr_step=0, thr_cost=0))
+    assert rows[0].iteration_status == orows[0].iteration_status
+    assert relerr(rows[0].trial_cost, orows[0].trial_cost) < 1e-8
+    assert relerr(rows[0].model_change, orows[0].model_change) < 1e-7
+    assert relerr(g.get_poses(), o.get_poses()) < RTOL_FINAL
+    assert relerr(g.get_points()[0], o.get_points()) < RTOL_FINAL
