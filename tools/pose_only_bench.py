@@ -35,3 +35,28 @@ for n in (10_000, 300_000):
           "cpu oracle %.3f ms  max|dT| %.2e" %
           (n, res["n_iter"], ref["n_iter"], np.median(ts) * 1e3,
            min(ts) * 1e3, tc * 1e3, np.abs(res["T12"] - ref["T12"]).max()))
+
+# stereo 6-DoF (Solve_Stereo_6Dof path), 20 % of the points without a right match
+for n in (10_000, 300_000):
+    sc = scenes.pose_only_stereo_scene(n, seed=2025, right_missing_frac=0.2)
+    intr = [sc["fx"], sc["fy"], sc["cx"], sc["cy"]]
+    to12 = lambda T: np.concatenate([T[:3, :3].reshape(9), T[:3, 3]])
+    opt = O.make_options(max_iter=100, thr_step=1e-6, thr_cost=1e-6, huber=1.0,
+                         outlier=2.5, cls=BaOptions)
+    oopt = O.make_options(max_iter=100, thr_step=1e-6, thr_cost=1e-6,
+                          huber=1.0, outlier=2.5)
+    ones = np.ones(n, np.uint8)
+    ts = []
+    for r in range(7):
+        t = time.perf_counter()
+        res = g.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
+                                  to12(sc["T_lr"]), to12(sc["T_init"]), ones, ones, opt)
+        ts.append(time.perf_counter() - t)
+    t = time.perf_counter()
+    ref = O.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
+                              sc["T_lr"], sc["T_init"], ones, ones, oopt)
+    tc = time.perf_counter() - t
+    print("stereo n=%d  iters gpu/cpu %d/%d  gpu call median %.3f ms (min %.3f)  "
+          "cpu oracle %.3f ms  max|dT| %.2e" %
+          (n, res["n_iter"], ref["n_iter"], np.median(ts) * 1e3,
+           min(ts) * 1e3, tc * 1e3, np.abs(res["T12"] - ref["T12"]).max()))
