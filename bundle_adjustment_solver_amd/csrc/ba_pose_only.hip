@@ -28,15 +28,30 @@ constexpr int kPoThreads = 1024;
 constexpr int kPoWaves = kPoThreads / 64;
 constexpr int kNred = 29;  // 21 upper H + 6 g + 1 err + 1 count of right-camera edges
 
+// Wave-wide fp32 sum on the DPP network (xor-1, xor-2, half-mirror, mirror leave
+// every lane with the total of its row of 16; the four row totals are added in
+// order).  Fixed association; every lane returns the total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_f32(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);  // row_half_mirror
+  v += dpp_f32<0x140>(v);  // row_mirror
+  return ((lane_f32(v, 0) + lane_f32(v, 16)) + lane_f32(v, 32)) + lane_f32(v, 48);
 }
 
 // Eigen-style pivoted LDL^T solve of a 6x6 system in fp32 (thread 0 only).
-__device__ void ldlt6_solve(float *m /*36, row-major, lower used*/, float *d) {
-  int tr[6];
+// m, d, tr, tmp point to LDS: the pivoted algorithm indexes them dynamically,
+// which would otherwise put them in scratch (global) memory.
+__device__ void ldlt6_solve(float *m /*36, row-major, lower used*/, float *d, int *tr,
+                            float *tmp) {
 #define AT(r, c) m[(r) * 6 + (c)]
   bool early = false;
   for (int k = 0; k < 6 && !early; ++k) {
@@ -66,7 +81,6 @@ __device__ void ldlt6_solve(float *m /*36, row-major, lower used*/, float *d) {
       }
     }
     const int rs = 6 - k - 1;
-    float tmp[6];
     if (k > 0) {
       float acc = 0.0f;
       for (int c = 0; c < k; ++c) {
@@ -161,6 +175,9 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
     float thr_huber, float thr_step, float thr_cost, float thr_out, int max_it,
     PoIter *iters, int cap, int *meta, float *debug_T12) {
   __shared__ float red[kPoWaves][kNred];
+  __shared__ float tots[kNred];
+  __shared__ float Hs[36], gs[6], tmps[6];
+  __shared__ int trs[6];
   __shared__ float pose[12];  // camera_to_world_optimized: R (9) then t (3)
   __shared__ int ctl[2];      // [0] = stop flag
   __shared__ float s_err_prev;
@@ -197,26 +214,40 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
 #pragma unroll
       for (int k = 0; k < 16; ++k) cr[k] = cam_r[k];
     }
-    for (int p = tid; p < n; p += kPoThreads) {
-      const float X0 = X3[3 * p], X1 = X3[3 * p + 1], X2 = X3[3 * p + 2];
-      float Lp[3];
+    // four points per trip: their loads are issued together, so a trip pays one
+    // memory latency instead of four (the inputs are re-read from L2 in every
+    // Gauss-Newton iteration)
+    for (int p0 = tid; p0 < n; p0 += 4 * kPoThreads) {
+      float Xb[4][3], ub[4][2], urb[4][2];
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-        Lp[r] = (Rl[r * 3 + 0] * X0 + Rl[r * 3 + 1] * X1 + Rl[r * 3 + 2] * X2) + tl[r];
-      po_edge(Lp, fx, fy, cx, cy, uv2[2 * p], uv2[2 * p + 1], thr_huber, thr_out, acc,
-              mask + p);
-      if (STEREO) {
-        const float pu = uvr2[2 * p], pv = uvr2[2 * p + 1];
-        if (!(pu < 0 || pv < 0)) {  // reference :298
-          float Lr[3];
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * kPoThreads;
+        const int pc = p < n ? p : n - 1;
+        Xb[u][0] = X3[3 * pc]; Xb[u][1] = X3[3 * pc + 1]; Xb[u][2] = X3[3 * pc + 2];
+        ub[u][0] = uv2[2 * pc]; ub[u][1] = uv2[2 * pc + 1];
+        if (STEREO) { urb[u][0] = uvr2[2 * pc]; urb[u][1] = uvr2[2 * pc + 1]; }
+      }
 #pragma unroll
-          for (int r = 0; r < 3; ++r)
-            Lr[r] = (cr[4 + r * 3 + 0] * Lp[0] + cr[4 + r * 3 + 1] * Lp[1] +
-                     cr[4 + r * 3 + 2] * Lp[2]) +
-                    cr[13 + r];
-          po_edge(Lr, cr[0], cr[1], cr[2], cr[3], pu, pv, thr_huber, thr_out, acc,
-                  maskr + p);
-          acc[28] += 1.0f;
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * kPoThreads;
+        if (p >= n) break;
+        float Lp[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          Lp[r] = (Rl[r * 3 + 0] * Xb[u][0] + Rl[r * 3 + 1] * Xb[u][1] + Rl[r * 3 + 2] * Xb[u][2]) + tl[r];
+        po_edge(Lp, fx, fy, cx, cy, ub[u][0], ub[u][1], thr_huber, thr_out, acc, mask + p);
+        if (STEREO) {
+          const float pu = urb[u][0], pv = urb[u][1];
+          if (!(pu < 0 || pv < 0)) {  // reference :298
+            float Lr[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+              Lr[r] = (cr[4 + r * 3 + 0] * Lp[0] + cr[4 + r * 3 + 1] * Lp[1] +
+                       cr[4 + r * 3 + 2] * Lp[2]) +
+                      cr[13 + r];
+            po_edge(Lr, cr[0], cr[1], cr[2], cr[3], pu, pv, thr_huber, thr_out, acc, maskr + p);
+            acc[28] += 1.0f;
+          }
         }
       }
     }
@@ -226,14 +257,20 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
       if (lane == 0) red[wv][k] = s;
     }
     __syncthreads();
+    // cross-wave sums in parallel (thread k adds the 16 wave totals of sum k in
+    // order), then thread 0 runs the 6x6 solve
+    if (tid < kNred) {
+      float sk = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kPoWaves; ++w) sk += red[w][tid];
+      tots[tid] = sk;
+    }
+    __syncthreads();
     if (tid == 0) {
       float tot[kNred];
-      for (int k = 0; k < kNred; ++k) {
-        float s = 0.0f;
-        for (int w = 0; w < kPoWaves; ++w) s += red[w][k];
-        tot[k] = s;
-      }
-      float H[36], g[6];
+#pragma unroll
+      for (int k = 0; k < kNred; ++k) tot[k] = tots[k];
+      float *H = Hs, *g = gs;
       int k = 0;
       for (int r = 0; r < 6; ++r)
         for (int c = r; c < 6; ++c) {
@@ -243,7 +280,7 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
         }
       for (int r = 0; r < 6; ++r) H[r * 6 + r] *= (1.0f + 1e-5f);  // :103
       for (int c = 0; c < 6; ++c) g[c] = tot[21 + c];
-      ldlt6_solve(H, g);  // delta_xi, reference :105
+      ldlt6_solve(H, g, trs, tmps);  // delta_xi, reference :105
       // se3 exponential, reference :1280-1316
       const float v0 = g[0], v1 = g[1], v2 = g[2], w0 = g[3], w1 = g[4], w2 = g[5];
       const float theta = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
