@@ -87,7 +87,8 @@ struct ba_handle {
   std::vector<int> pose_col_h;
   // pose-only scratch (grown on demand, reused across calls)
   int po_cap_n = 0, po_cap_it = 0;
-  float *po_uvr = nullptr, *po_camr = nullptr;
+  float *po_uvr = nullptr, *po_camr = nullptr, *po_part = nullptr;
+  int *po_gsync = nullptr;
   uint8_t *po_maskr = nullptr;
   int po_cap_nr = 0;
   float *po_X = nullptr, *po_uv = nullptr, *po_T = nullptr, *po_dbg = nullptr;
@@ -1089,7 +1090,9 @@ int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
   if (icap > h->po_cap_it || !h->po_T) {
     if (h->dalloc(&h->po_iters, (size_t)icap) || h->dalloc(&h->po_dbg, (size_t)icap * 12))
       return -1;
-    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4)))
+    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4) ||
+                     h->dalloc(&h->po_gsync, (size_t)ba::pose_only_sync_ints()) ||
+                     h->dalloc(&h->po_part, (size_t)ba::pose_only_partial_floats())))
       return -1;
     h->po_cap_it = icap;
   }
@@ -1102,13 +1105,15 @@ int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
                                  opt->threshold_huber_loss, opt->threshold_step_size,
                                  opt->threshold_cost_change, opt->threshold_outlier_rejection,
                                  max_it, h->po_iters, icap, h->po_meta,
-                                 debug_T12 ? h->po_dbg : nullptr, s))
+                                 debug_T12 ? h->po_dbg : nullptr, h->po_gsync, h->po_part, s))
     return fail("pose-only kernel launch failed");
-  int meta[4] = {0, 0, 0, 0};
+  int meta[4] = {0, 0, 0, 0}, gsw[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(meta, h->po_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(gsw, h->po_gsync, sizeof(gsw), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(T12, h->po_T, 12 * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(mask, h->po_mask, (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (gsw[1]) return fail("pose-only kernel: grid barrier timed out");
   if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
   const int rows = std::min(meta[2], cap);
   if (iters && rows > 0)
@@ -1159,7 +1164,9 @@ int ba_pose_only_stereo6(ba_handle *h, const float *X3, const float *uv2,
   if (icap > h->po_cap_it || !h->po_T) {
     if (h->dalloc(&h->po_iters, (size_t)icap) || h->dalloc(&h->po_dbg, (size_t)icap * 12))
       return -1;
-    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4)))
+    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4) ||
+                     h->dalloc(&h->po_gsync, (size_t)ba::pose_only_sync_ints()) ||
+                     h->dalloc(&h->po_part, (size_t)ba::pose_only_partial_floats())))
       return -1;
     h->po_cap_it = icap;
   }
@@ -1176,14 +1183,16 @@ int ba_pose_only_stereo6(ba_handle *h, const float *X3, const float *uv2,
                                  opt->threshold_huber_loss, opt->threshold_step_size,
                                  opt->threshold_cost_change, opt->threshold_outlier_rejection,
                                  max_it, h->po_iters, icap, h->po_meta,
-                                 debug_T12 ? h->po_dbg : nullptr, s))
+                                 debug_T12 ? h->po_dbg : nullptr, h->po_gsync, h->po_part, s))
     return fail("pose-only kernel launch failed");
-  int meta[4] = {0, 0, 0, 0};
+  int meta[4] = {0, 0, 0, 0}, gsw[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(meta, h->po_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(gsw, h->po_gsync, sizeof(gsw), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(T12, h->po_T, 12 * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(mask, h->po_mask, (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(mask_r, h->po_maskr, (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (gsw[1]) return fail("pose-only kernel: grid barrier timed out");
   if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
   const int rows = std::min(meta[2], cap);
   if (iters && rows > 0)

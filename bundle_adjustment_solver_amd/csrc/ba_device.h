@@ -224,18 +224,20 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
 struct PoIter {
   float cost, cost_change, abs_step;
 };
+int pose_only_sync_ints();       // size of the grid-barrier words (ints)
+int pose_only_partial_floats();  // size of the partial-sum exchange buffer (floats)
 int pose_only_mono6_device(const float *dX3, const float *duv2, int n, float fx,
-                           float fy, float cx, float cy, float *dT12_inout,
+                           float fy, float cx, float cy, float *dT12,
                            uint8_t *dmask, float thr_huber, float thr_step,
                            float thr_cost, float thr_out, int max_it,
                            PoIter *d_iters, int cap, int *d_meta,
-                           float *d_debug, hipStream_t s);
+                           float *d_debug, int *d_gsync, float *d_partial, hipStream_t s);
 int pose_only_stereo6_device(const float *dX3, const float *duvl2, const float *duvr2, int n,
                              float fx, float fy, float cx, float cy, const float *d_cam_r16,
                              float *dT12, uint8_t *dmask_l, uint8_t *dmask_r, float thr_huber,
                              float thr_step, float thr_cost, float thr_out, int max_it,
                              PoIter *d_iters, int cap, int *d_meta, float *d_debug,
-                             hipStream_t s);
+                             int *d_gsync, float *d_partial, hipStream_t s);
 
 }  // namespace ba
 #endif

@@ -26,6 +26,8 @@ namespace {
 
 constexpr int kPoThreads = 1024;
 constexpr int kPoWaves = kPoThreads / 64;
+constexpr int kPoMaxGroups = 64;   // workgroups of one launch (all co-resident)
+constexpr int kPoPointsPerThread = 2;  // aimed at when choosing the group count
 constexpr int kNred = 29;  // 21 upper H + 6 g + 1 err + 1 count of right-camera edges
 
 // Wave-wide fp32 sum on the DPP network (xor-1, xor-2, half-mirror, mirror leave
@@ -167,13 +169,45 @@ __device__ __forceinline__ void po_edge(const float Lp[3], float fx, float fy, f
 // meta[3] = success (0 = NaN)
 // STEREO: uvr2 = right pixels, cam_r = {fx,fy,cx,cy, Rrl(9), trl(3)} with
 // (Rrl, trl) = left_to_right^-1, maskr = right inlier mask.
+// Grid-wide barrier of the co-resident workgroups of ONE launch (gridDim.x <=
+// kPoMaxGroups workgroups of 1024 threads always fit the 256 CUs at once).
+// gsync[0] counts arrivals, monotonically: barrier number b is passed when it
+// reaches (b+1)*gridDim.x.  The release add publishes this workgroup's partial
+// sums, the acquire load makes the others' visible (and invalidates the CU's
+// L1 for every wave of the workgroup).  The spin is bounded: on a time-out
+// gsync[1] is set and the kernel still runs to its end, so the grid always
+// drains; the host then reports an error.
+__device__ __forceinline__ void po_grid_barrier(int *gsync, int target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&gsync[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(&gsync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1 << 22)) {
+        gsync[1] = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+}
+
+// Several workgroups (one per CU) share the points of one problem: each
+// linearises its share, the 29 partial sums meet in `partial` (double-buffered
+// by iteration parity), ONE grid barrier per Gauss-Newton iteration, and then
+// EVERY workgroup adds the partials in the same order and runs the same 6x6
+// solve, so all hold the same pose and take the same convergence decision
+// without a second barrier or a broadcast.  Workgroup 0 writes the outputs.
 template <bool STEREO>
 __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
     const float *__restrict__ X3, const float *__restrict__ uv2,
     const float *__restrict__ uvr2, int n, float fx, float fy, float cx, float cy,
     const float *__restrict__ cam_r, float *T12, uint8_t *mask, uint8_t *maskr,
     float thr_huber, float thr_step, float thr_cost, float thr_out, int max_it,
-    PoIter *iters, int cap, int *meta, float *debug_T12) {
+    PoIter *iters, int cap, int *meta, float *debug_T12, int *gsync, float *partial) {
+  const int G = gridDim.x;
+  const bool lead = blockIdx.x == 0;
   __shared__ float red[kPoWaves][kNred];
   __shared__ float tots[kNred];
   __shared__ float Hs[36], gs[6], tmps[6];
@@ -192,12 +226,16 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
       pose[9 + r] = -(R[r * 3 + 0] * T12[9] + R[r * 3 + 1] * T12[10] +
                       R[r * 3 + 2] * T12[11]);
     ctl[0] = 0;
+    ctl[1] = 0;  // iterations executed
     s_err_prev = 1e10f;
-    meta[0] = 0;
-    meta[1] = 1;
-    meta[2] = 0;
-    meta[3] = 1;
+    if (lead) {
+      meta[0] = 0;
+      meta[1] = 1;
+      meta[2] = 0;
+      meta[3] = 1;
+    }
   }
+  int n_rows = 0;  // Summary rows logged so far (thread 0)
   __syncthreads();
   const float inv_n = 1.0f / (float)n;
   for (int it = 0; it < max_it; ++it) {
@@ -217,11 +255,12 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
     // four points per trip: their loads are issued together, so a trip pays one
     // memory latency instead of four (the inputs are re-read from L2 in every
     // Gauss-Newton iteration)
-    for (int p0 = tid; p0 < n; p0 += 4 * kPoThreads) {
+    const int gstride = G * kPoThreads;
+    for (int p0 = blockIdx.x * kPoThreads + tid; p0 < n; p0 += 4 * gstride) {
       float Xb[4][3], ub[4][2], urb[4][2];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int p = p0 + u * kPoThreads;
+        const int p = p0 + u * gstride;
         const int pc = p < n ? p : n - 1;
         Xb[u][0] = X3[3 * pc]; Xb[u][1] = X3[3 * pc + 1]; Xb[u][2] = X3[3 * pc + 2];
         ub[u][0] = uv2[2 * pc]; ub[u][1] = uv2[2 * pc + 1];
@@ -229,7 +268,7 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int p = p0 + u * kPoThreads;
+        const int p = p0 + u * gstride;
         if (p >= n) break;
         float Lp[3];
 #pragma unroll
@@ -264,6 +303,16 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
 #pragma unroll
       for (int w = 0; w < kPoWaves; ++w) sk += red[w][tid];
       tots[tid] = sk;
+    }
+    if (G > 1) {
+      float *pb = partial + (size_t)(it & 1) * kPoMaxGroups * kNred;
+      if (tid < kNred) pb[blockIdx.x * kNred + tid] = tots[tid];
+      po_grid_barrier(gsync, (it + 1) * G);
+      if (tid < kNred) {  // every workgroup: the same sum in the same order
+        float sk = 0.0f;
+        for (int w = 0; w < G; ++w) sk += pb[w * kNred + tid];
+        tots[tid] = sk;
+      }
     }
     __syncthreads();
     if (tid == 0) {
@@ -316,7 +365,7 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
       }
       for (int q = 0; q < 9; ++q) pose[q] = Rn[q];
       for (int q = 0; q < 3; ++q) pose[9 + q] = tn[q];
-      if (debug_T12 && it < cap) {
+      if (lead && debug_T12 && it < cap) {
         float *D = debug_T12 + 12 * it;
         for (int r = 0; r < 3; ++r)
           for (int c = 0; c < 3; ++c) D[r * 3 + c] = Rn[c * 3 + r];
@@ -328,26 +377,29 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
                                     : tot[27] * (inv_n * 0.5f);
       const float delta_error = fabsf(err_curr - s_err_prev);
       const float dn = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + w0 * w0 + w1 * w1 + w2 * w2);
-      meta[0] = it + 1;
+      ctl[1] = it + 1;
+      if (lead) meta[0] = it + 1;
       if (dn < thr_step || delta_error < thr_cost) {
-        meta[1] = 1;
+        if (lead) meta[1] = 1;
         ctl[0] = 1;  // converged: no Summary row (reference :116-121)
       } else {
-        if (it == max_it - 1) meta[1] = 0;
-        const int row = meta[2];
-        if (iters && row < cap) {
-          iters[row].cost = err_curr;
-          iters[row].cost_change = delta_error;
-          iters[row].abs_step = dn;
+        if (lead && it == max_it - 1) meta[1] = 0;
+        if (lead && iters && n_rows < cap) {
+          iters[n_rows].cost = err_curr;
+          iters[n_rows].cost_change = delta_error;
+          iters[n_rows].abs_step = dn;
         }
-        meta[2] = row + 1;
+        ++n_rows;
+        if (lead) meta[2] = n_rows;
         s_err_prev = err_curr;
       }
     }
     __syncthreads();
     if (ctl[0]) break;
   }
-  if (tid == 0) {
+  // (with no iteration executed nothing was exchanged: T12 stays as given, and
+  //  no workgroup may write it while another still reads it)
+  if (tid == 0 && lead && ctl[1] > 0) {
     float nrm = 0.0f;
     for (int k = 0; k < 9; ++k) nrm += pose[k] * pose[k];
     if (isnan(nrm)) {
@@ -364,16 +416,25 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
 
 }  // namespace
 
+// workgroups for n points: about kPoPointsPerThread points per thread
+static int po_groups(int n) {
+  int g = (n + kPoThreads * kPoPointsPerThread - 1) / (kPoThreads * kPoPointsPerThread);
+  return g < 1 ? 1 : (g > kPoMaxGroups ? kPoMaxGroups : g);
+}
+int pose_only_sync_ints() { return 2; }
+int pose_only_partial_floats() { return 2 * kPoMaxGroups * kNred; }
+
 int pose_only_mono6_device(const float *dX3, const float *duv2, int n, float fx,
                            float fy, float cx, float cy, float *dT12,
                            uint8_t *dmask, float thr_huber, float thr_step,
                            float thr_cost, float thr_out, int max_it,
                            PoIter *d_iters, int cap, int *d_meta,
-                           float *d_debug, hipStream_t s) {
-  hipLaunchKernelGGL(k_pose_only6<false>, dim3(1), dim3(kPoThreads), 0, s, dX3, duv2,
+                           float *d_debug, int *d_gsync, float *d_partial, hipStream_t s) {
+  if (hipMemsetAsync(d_gsync, 0, 2 * sizeof(int), s) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_pose_only6<false>, dim3(po_groups(n)), dim3(kPoThreads), 0, s, dX3, duv2,
                      (const float *)nullptr, n, fx, fy, cx, cy, (const float *)nullptr, dT12,
                      dmask, (uint8_t *)nullptr, thr_huber, thr_step, thr_cost, thr_out, max_it,
-                     d_iters, cap, d_meta, d_debug);
+                     d_iters, cap, d_meta, d_debug, d_gsync, d_partial);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -382,10 +443,12 @@ int pose_only_stereo6_device(const float *dX3, const float *duvl2, const float *
                              float *dT12, uint8_t *dmask_l, uint8_t *dmask_r, float thr_huber,
                              float thr_step, float thr_cost, float thr_out, int max_it,
                              PoIter *d_iters, int cap, int *d_meta, float *d_debug,
-                             hipStream_t s) {
-  hipLaunchKernelGGL(k_pose_only6<true>, dim3(1), dim3(kPoThreads), 0, s, dX3, duvl2, duvr2, n,
-                     fx, fy, cx, cy, d_cam_r16, dT12, dmask_l, dmask_r, thr_huber, thr_step,
-                     thr_cost, thr_out, max_it, d_iters, cap, d_meta, d_debug);
+                             int *d_gsync, float *d_partial, hipStream_t s) {
+  if (hipMemsetAsync(d_gsync, 0, 2 * sizeof(int), s) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_pose_only6<true>, dim3(po_groups(n)), dim3(kPoThreads), 0, s, dX3, duvl2,
+                     duvr2, n, fx, fy, cx, cy, d_cam_r16, dT12, dmask_l, dmask_r, thr_huber,
+                     thr_step, thr_cost, thr_out, max_it, d_iters, cap, d_meta, d_debug, d_gsync,
+                     d_partial);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
