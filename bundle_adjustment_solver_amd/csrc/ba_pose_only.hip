@@ -7,11 +7,12 @@
 // sees X_r = left_to_right^-1 * X_l, contributes where its pixel is
 // non-negative, has its own inlier mask; the error is normalised by
 // (count_left + count_right) * 0.5f).  The whole GN loop runs inside ONE persistent
-// workgroup launch (the problem is 10 k points ~ 200 KB: launch / PCIe latency
-// dominates, not bandwidth): per iteration every thread linearises its points,
-// the 21+6+1 sums are reduced through shuffles + LDS, thread 0 solves the 6x6
-// system with the pivoted LDL^T the reference gets from Eigen and composes the
-// se3 exponential onto the pose held in LDS.
+// launch of up to 64 co-resident workgroups (the problem is 10 k points ~ 200 KB:
+// launch / PCIe latency dominates, not bandwidth): per iteration every thread
+// linearises its points, the 21+6+1+1 sums are reduced through DPP + LDS and,
+// across workgroups, through one grid barrier; thread 0 of every workgroup solves
+// the 6x6 system with the pivoted LDL^T the reference gets from Eigen and
+// composes the se3 exponential onto the pose held in LDS.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -306,11 +307,15 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_only6(
     }
     if (G > 1) {
       float *pb = partial + (size_t)(it & 1) * kPoMaxGroups * kNred;
-      if (tid < kNred) pb[blockIdx.x * kNred + tid] = tots[tid];
+      // agent-scope accesses: the partials cross XCDs (separate L2s)
+      if (tid < kNred)
+        __hip_atomic_store(&pb[blockIdx.x * kNred + tid], tots[tid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
       po_grid_barrier(gsync, (it + 1) * G);
       if (tid < kNred) {  // every workgroup: the same sum in the same order
         float sk = 0.0f;
-        for (int w = 0; w < G; ++w) sk += pb[w * kNred + tid];
+        for (int w = 0; w < G; ++w)
+          sk += __hip_atomic_load(&pb[w * kNred + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tots[tid] = sk;
       }
     }
