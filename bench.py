@@ -95,11 +95,21 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # BA_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs
+    # than ranks (ranks share cards, the exchange is staged through the host);
+    # the line is then labelled as a rehearsal, never a result.
+    backend = os.environ.get("BA_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    if rehearsal:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     ge.build(only_if_missing=True)
@@ -128,7 +138,8 @@ def main():
     t_fin = time.time() - t_fin
     if world > 1:
         from bundle_adjustment_solver_amd.sharding import TorchExchange
-        keep.append(TorchExchange(p, dist, torch.device("cuda", local_rank)))
+        keep.append(TorchExchange(p, dist, torch.device("cuda", local_rank),
+                                  stage_host=rehearsal))
 
     n_obs = int(pr["obs_cam"].shape[0])
     N = p.N
@@ -153,7 +164,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64,
+                          device="cpu" if rehearsal else "cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     rows, n_done, conv, done = p.lm_sync(cap=args.warmup + args.steps + 1)
@@ -178,7 +190,9 @@ def main():
             ("" if args.scale == 1.0 else " (scaled x%g, debug)" % args.scale),
             "n_opt_poses": N, "n_opt_landmarks": M_glob,
             "n_observations": n_obs,
-            "parallelism": "landmark-shard x%d + all-reduce(S|rhs)" % world
+            "parallelism": ("landmark-shard x%d + all-reduce(S|rhs)" % world +
+                            (" (REHEARSAL: %s, shared GPU)" % backend
+                             if rehearsal else ""))
             if world > 1 else "single GPU",
         },
         "obs_iterations_per_sec": n_obs * args.steps / elapsed,

@@ -46,9 +46,12 @@ class TorchExchange:
     """Owns the two exchange buffers as torch tensors, binds them into a
     BaProblem and serves the all-reduce hook with torch.distributed."""
 
-    def __init__(self, problem, dist, device):
+    def __init__(self, problem, dist, device, stage_host=False):
         import torch
         self.dist = dist
+        # stage_host: all-reduce a host copy (a backend without device
+        # collectives, e.g. gloo when several ranks rehearse on one card)
+        self.stage_host = stage_host
         self.bufs = []
         for which in (0, 1):
             n = problem.reduce_buffer_size(which)
@@ -59,5 +62,10 @@ class TorchExchange:
 
     def hook(self, which, ptr, n, stream):
         # issued on torch's current stream == the stream the kernels run on
-        self.dist.all_reduce(self.bufs[which])
+        if self.stage_host:
+            h = self.bufs[which].cpu()
+            self.dist.all_reduce(h)
+            self.bufs[which].copy_(h)
+        else:
+            self.dist.all_reduce(self.bufs[which])
         return 0
