@@ -884,16 +884,25 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
     __syncthreads();
     DBG_STAMP()
     if (owner) {
+      // The triple word carries everything the iteration needs (pair p, pair q,
+      // local landmark), and the word of the NEXT iteration is read one
+      // iteration ahead: otherwise every iteration starts with two dependent
+      // LDS round trips (word -> landmark index -> b) before its 27 reads.
       const int t1 = (int)Sp[slot + 1];
-      for (int t = (int)Sp[slot] + sub2; t < t1; t += tps2) {
-        const uint32_t pq = Ts[t];
-        const double *vp = Vs + (pq >> 16) * 18 + h * 9;  // rows 3h..3h+2 of V
-        const double2 *wp = (const double2 *)(Ws + (pq & 0xffffu) * 18);
-        // diagonal triple (p == q): also B Cinv b of this pair (reference :864)
-        const bool dg = (pq >> 16) == (pq & 0xffffu);
-        const double *bp = Bs + (int)Pl[pq >> 16] * 3;
-        const double b0 = dg ? bp[0] : 0.0, b1 = dg ? bp[1] : 0.0,
-                     b2 = dg ? bp[2] : 0.0;
+      int t = (int)Sp[slot] + sub2;
+      uint32_t pq = Ts[t < kSchurTri ? t : kSchurTri - 1];
+      while (t < t1) {
+        const int tn = t + tps2;
+        const uint32_t pqn = Ts[tn < kSchurTri ? tn : kSchurTri - 1];  // unused past t1
+        __builtin_amdgcn_sched_barrier(0);  // keep the read up here
+        const uint32_t pp = pq >> 16, qq = pq & 0xffu;
+        const double *vp = Vs + pp * 18 + h * 9;  // rows 3h..3h+2 of V
+        const double2 *wp = (const double2 *)(Ws + qq * 18);
+        // diagonal triple (p == q): also B Cinv b of this pair (reference :864);
+        // b is read unconditionally and masked (no divergent LDS reads)
+        const double *bp = Bs + ((pq >> 8) & 0xffu) * 3;
+        const double bm = (pp == qq) ? 1.0 : 0.0;
+        const double b0 = bp[0] * bm, b1 = bp[1] * bm, b2 = bp[2] * bm;
         double w[18];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -911,6 +920,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
                                      fma(v0, w[c * 3 + 0], acc[r * 6 + c])));
           racc[r] = fma(v2, b2, fma(v1, b1, fma(v0, b0, racc[r])));
         }
+        pq = pqn;
+        t = tn;
       }
     }
     DBG_STAMP()

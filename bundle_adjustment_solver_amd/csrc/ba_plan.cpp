@@ -472,7 +472,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           for (int64_t p = pl.lm_pair_ptr[m]; p < pl.lm_pair_ptr[m + 1]; ++p)
             for (int64_t q = p; q < pl.lm_pair_ptr[m + 1]; ++q)
               loc.push_back({mark[block_of(pl.pair_pose[p], pl.pair_pose[q])],
-                             (uint32_t)(((p - pbase) << 16) | (q - pbase))});
+                             (uint32_t)(((p - pbase) << 16) | ((uint32_t)(m - c0) << 8) |
+                                        (q - pbase))});
         std::stable_sort(loc.begin(), loc.end(),
                          [](const auto &x, const auto &y) { return x.first < y.first; });
         Plan::ChunkDesc cd;

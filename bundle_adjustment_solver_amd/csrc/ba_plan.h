@@ -41,6 +41,7 @@ constexpr int kPoseWaveTarget = 8192;
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
 constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
 constexpr int kSchurLandmarks = 128;  // landmarks per chunk
+static_assert(kSchurPairs <= 256 && kSchurLandmarks <= 256, "triple words hold 8-bit local indices");
 constexpr int kSchurTri = 1024;       // triples per chunk (LDS resident)
 constexpr int kSchurSlots = 128;      // distinct blocks per super-run (>= 2 lanes each)
 constexpr int kSchurSuperLandmarks = 256;  // landmarks per super-run (upper bound)
@@ -112,7 +113,7 @@ struct Plan {
   std::vector<ChunkDesc> chunk_desc;
   std::vector<uint16_t> chunk_sp;        // per chunk: ns+1 slot offsets
   std::vector<int32_t> slot_blk;         // block of each slot
-  std::vector<uint32_t> ltri;            // (local pair p << 16) | local pair q
+  std::vector<uint32_t> ltri;            // (local pair p << 16) | (local landmark << 8) | local pair q
   std::vector<int64_t> blk_contrib_ptr;  // B+1 -> contrib_slot
   std::vector<int32_t> contrib_slot;     // slots of each block, workgroup order
   std::vector<int32_t> bchunk_lm;        // landmark ranges of the backsub chunks
