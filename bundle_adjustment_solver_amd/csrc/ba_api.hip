@@ -477,7 +477,7 @@ int ba_finalize(ba_handle *h) {
   // per-iteration storage
   if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.b, (size_t)pl.M * 3) ||
       h->dalloc(&d.Cinv, (size_t)pl.M * 6) || h->dalloc(&d.Cinvb, (size_t)pl.M * 3) ||
-      h->dalloc(&d.W, (size_t)pl.P * 18) ||
+      h->dalloc(&d.W, (size_t)pl.P * ba::kWStride) ||
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) || h->dalloc(&d.A, (size_t)pl.N * 36) ||
       h->dalloc(&d.a, (size_t)pl.N * 6) ||
       h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
@@ -485,7 +485,7 @@ int ba_finalize(ba_handle *h) {
       h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_bchunk) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
       h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
     return -1;
-  HIP_TRY(hipMemset(d.W, 0, std::max<size_t>(1, (size_t)pl.P * 18) * sizeof(double)));
+  HIP_TRY(hipMemset(d.W, 0, std::max<size_t>(1, (size_t)pl.P * ba::kWStride) * sizeof(double)));
   HIP_TRY(hipMemset(d.x, 0, ((size_t)pl.N * 6 + 64) * sizeof(double)));
   HIP_TRY(hipMemset(d.y, 0, std::max<size_t>(1, (size_t)pl.M * 3) * sizeof(double)));
   HIP_TRY(hipMemset(d.cost_part, 0, ba::kCostGrid * sizeof(double)));
@@ -911,8 +911,20 @@ int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18) {
   }
   if (W18) {
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // the device keeps B_ji compact ({K, X_ij}, ba_device.h kWStride): expand
+    std::vector<double> w12((size_t)pl.P * ba::kWStride);
     if (pl.P > 0)
-      HIP_TRY(hipMemcpy(W18, h->d.W, (size_t)pl.P * 18 * sizeof(double), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(w12.data(), h->d.W, w12.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t p = 0; p < pl.P; ++p) {
+      const double *k = &w12[(size_t)p * ba::kWStride];
+      double *W = W18 + (size_t)p * 18;
+      for (int e = 0; e < 9; ++e) W[e] = k[e];
+      for (int c = 0; c < 3; ++c) {
+        W[9 + c] = k[10] * k[6 + c] - k[11] * k[3 + c];
+        W[12 + c] = k[11] * k[c] - k[9] * k[6 + c];
+        W[15 + c] = k[9] * k[3 + c] - k[10] * k[c];
+      }
+    }
   }
   return 0;
 }

@@ -39,6 +39,13 @@ struct DevIterRec {  // layout-identical to ba_iter_info
 };
 
 // All device pointers of one problem shard.
+// B_ji = w Q^T R (6x3, reference :826) has the structure [K ; [X_ij]x K] with
+// K = w G^T R (3x3, = rows 0..2 of B_ji bit for bit) and X_ij the point in the
+// pose frame: Q = [G, G(-[X_ij]x)].  HBM holds the 12 doubles {K row-major,
+// X_ij} per pair (96 B instead of 144); consumers rebuild rows 3..5 as
+// X_ij x (column of K), or use B^T x = K^T (x_t + x_r x X_ij) directly.
+constexpr int kWStride = 12;
+
 struct DevProblem {
   // sizes
   int n_cam, n_pose, N, n_pt, M, M_global;
@@ -90,7 +97,7 @@ struct DevProblem {
   double *b;       // M*3
   double *Cinv;    // M*6   symmetric inverse upper
   double *Cinvb;   // M*3
-  double *W;       // P*18  B_ji 6x3 row-major
+  double *W;       // P*kWStride  compact B_ji (see kWStride)
   double *Apart;   // n_achunk*27
   double *A;       // N*36  damped, full
   double *a;       // N*6

@@ -218,6 +218,20 @@ __device__ __forceinline__ void make_R(const double G[6],
                       G[r * 3 + 2] * T[2 * 3 + c];
 }
 
+// rows 3..5 of B_ji from its compact record {K (9), X_ij (3)}: row 3+a, column c
+// = (X_ij x K[:,c])[a]
+__device__ __forceinline__ void expand_W(const double *__restrict__ k12, double W[18]) {
+#pragma unroll
+  for (int e = 0; e < 9; ++e) W[e] = k12[e];
+  const double X0 = k12[9], X1 = k12[10], X2 = k12[11];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    W[9 + c] = X1 * k12[6 + c] - X2 * k12[3 + c];
+    W[12 + c] = X2 * k12[c] - X0 * k12[6 + c];
+    W[15 + c] = X0 * k12[3 + c] - X1 * k12[c];
+  }
+}
+
 // Symmetric 3x3 inverse by diagonally pivoted LDL^T with D pseudo-inverted —
 // the behaviour of Eigen's C.ldlt().solve(I) (reference :854): an all-zero
 // C_i (never-observed landmark) yields Cinv = 0, not NaN.
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
   int ll_n = 0;
 #endif
   LL_STAMP()
-  __shared__ __attribute__((aligned(16))) double Wst[kSchurPairs * 18];
+  __shared__ __attribute__((aligned(16))) double Wst[kSchurPairs * kWStride];
   __shared__ double Cb[kBlock * 9];
   __shared__ double cams_s[kCamLds * 16];
   __shared__ int lq[kSchurLandmarks + 1];  // landmark observation offsets in the chunk
@@ -479,17 +493,18 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
       cb[8] = Rm[2] * wr0 + Rm[5] * wr1;
       if (id.w >= 0) {
         // B_ji = w Q^T R, kept only from the last-inserted observation of the
-        // pair (reference :826)
-        double Q[12];
-        make_Q(G, g.Xij, Q);
+        // pair (reference :826), stored compact: K = w G^T R (its rows
+        // 0..2) and X_ij (ba_device.h kWStride)
         const int lp = (int)(id.w - pb);
-        double *Wp = (lp < kSchurPairs) ? (Wst + lp * 18)
-                                        : (d.W + (size_t)id.w * 18);
+        double *Wp = (lp < kSchurPairs) ? (Wst + lp * kWStride)
+                                        : (d.W + (size_t)id.w * kWStride);
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c)
-            Wp[r * 3 + c] = w * (Q[r] * Rm[c] + Q[6 + r] * Rm[3 + c]);
+            Wp[r * 3 + c] = w * (G[r] * Rm[c] + G[3 + r] * Rm[3 + c]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Wp[9 + r] = g.Xij[r];
       }
     }
     LL_STAMP()
@@ -532,10 +547,10 @@ __global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
   }
   // W image -> global (contiguous)
   {
-    const int n2 = min(npair, kSchurPairs) * 9;
+    const int n2 = min(npair, kSchurPairs) * (kWStride / 2);
     const double2 *src = (const double2 *)Wst;
-    double2 *dst = (double2 *)(d.W + (size_t)pb * 18);
-    constexpr int kIt = (kSchurPairs * 9 + kBlock - 1) / kBlock;
+    double2 *dst = (double2 *)(d.W + (size_t)pb * kWStride);
+    constexpr int kIt = (kSchurPairs * (kWStride / 2) + kBlock - 1) / kBlock;
     double2 wv[kIt];
 #pragma unroll
     for (int k = 0; k < kIt; ++k) {
@@ -713,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
 // LDS, so HBM latency is hidden.  One reduction over the tps lanes and one
 // 288-byte store per slot at the very end; slots of one block are summed
 // across super-runs by k_schur_final in run order: deterministic, no atomics.
-constexpr int kSchurRW = (kSchurPairs * 9 + kBlock - 1) / kBlock;
+constexpr int kSchurRW = (kSchurPairs * (kWStride / 2) + kBlock - 1) / kBlock;
 constexpr int kSchurRC = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
 constexpr int kSchurRT = (kSchurTri + kBlock - 1) / kBlock;
 constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
@@ -721,10 +736,10 @@ constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
 // issue the (contiguous, independent) global loads of one chunk into registers
 #define SCHUR_PREFETCH(cd_)                                                   \
   {                                                                           \
-    const double2 *src_ = (const double2 *)(d.W + (size_t)(cd_).p0 * 18);     \
+    const double2 *src_ = (const double2 *)(d.W + (size_t)(cd_).p0 * kWStride); \
     _Pragma("unroll") for (int k_ = 0; k_ < kSchurRW; ++k_) {                 \
       const int t_ = tid + k_ * kBlock;                                       \
-      rw[k_] = (t_ < (cd_).np * 9) ? src_[t_] : make_double2(0.0, 0.0);       \
+      rw[k_] = (t_ < (cd_).np * 6) ? src_[t_] : make_double2(0.0, 0.0);       \
     }                                                                         \
     const double2 *cs_ = (const double2 *)(d.Cinv + (size_t)(cd_).l0 * 6);    \
     _Pragma("unroll") for (int k_ = 0; k_ < kSchurRC; ++k_) {                 \
@@ -814,11 +829,14 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   for (int ch = sd.chunk_begin; ch < sd.chunk_end; ++ch) {
     // registers -> LDS
     {
+      // compact record {K, X_ij} of pair p -> the first 12 doubles of its
+      // 18-double W image (K IS rows 0..2; X_ij is replaced by rows 3..5 below)
       double2 *dst = (double2 *)Ws;
 #pragma unroll
       for (int k = 0; k < kSchurRW; ++k) {
         const int t = tid + k * kBlock;
-        if (t < cd.np * 9) dst[t] = rw[k];
+        const int pr = t / 6;
+        if (t < cd.np * 6) dst[pr * 9 + (t - pr * 6)] = rw[k];
       }
       double2 *cdst = (double2 *)Cs;
 #pragma unroll
@@ -855,28 +873,46 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
     DBG_STAMP()
     __syncthreads();
     DBG_STAMP()
-    // V = W Cinv from LDS: one thread per (pair, row)
+    // Rows 3..5 of W (= X_ij x columns of K) and V = W Cinv, from LDS: thread p
+    // does rows 0..2 of pair p, thread 128 + p rows 3..5 (the only reader of the
+    // X_ij it overwrites).  kBlock == 2 * kSchurPairs.
     {
-      constexpr int kIt = (kSchurPairs * 6 + kBlock - 1) / kBlock;
-      double wv[kIt][3], cv[kIt][6];
+      static_assert(kBlock == 2 * kSchurPairs && (kSchurPairs & (kSchurPairs - 1)) == 0, "V phase mapping");
+      const int pr = tid & (kSchurPairs - 1);
+      const bool hi = tid >= kSchurPairs;  // wave-uniform
+      if (pr < np) {
+        const double *kk = Ws + pr * 18;
+        const double *ci = Cs + (int)Pl[pr] * 6;
+        double k9[9], c6[6], x3[3], wr[9];
 #pragma unroll
-      for (int k = 0; k < kIt; ++k) {  // all LDS reads first, then the arithmetic
-        const int t = tid + k * kBlock;
-        const bool on = t < np * 6;
-        const double *w = Ws + (on ? t : 0) * 3;
-        const double *ci = Cs + (on ? (int)Pl[t / 6] : 0) * 6;
+        for (int e = 0; e < 9; ++e) k9[e] = kk[e];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) wv[k][e] = w[e];
+        for (int e = 0; e < 6; ++e) c6[e] = ci[e];
+        if (hi) {
 #pragma unroll
-        for (int e = 0; e < 6; ++e) cv[k][e] = ci[e];
-      }
+          for (int e = 0; e < 3; ++e) x3[e] = kk[9 + e];
 #pragma unroll
-      for (int k = 0; k < kIt; ++k) {
-        const int t = tid + k * kBlock;
-        if (t < np * 6) {
-          Vs[t * 3 + 0] = wv[k][0] * cv[k][0] + wv[k][1] * cv[k][1] + wv[k][2] * cv[k][2];
-          Vs[t * 3 + 1] = wv[k][0] * cv[k][1] + wv[k][1] * cv[k][3] + wv[k][2] * cv[k][4];
-          Vs[t * 3 + 2] = wv[k][0] * cv[k][2] + wv[k][1] * cv[k][4] + wv[k][2] * cv[k][5];
+          for (int c = 0; c < 3; ++c) {
+            wr[c] = x3[1] * k9[6 + c] - x3[2] * k9[3 + c];
+            wr[3 + c] = x3[2] * k9[c] - x3[0] * k9[6 + c];
+            wr[6 + c] = x3[0] * k9[3 + c] - x3[1] * k9[c];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 9; ++e) wr[e] = k9[e];
+        }
+        double *wo = Ws + pr * 18 + 9, *vo = Vs + pr * 18 + (hi ? 9 : 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double w0 = wr[r * 3], w1 = wr[r * 3 + 1], w2 = wr[r * 3 + 2];
+          if (hi) {
+            wo[r * 3] = w0;
+            wo[r * 3 + 1] = w1;
+            wo[r * 3 + 2] = w2;
+          }
+          vo[r * 3 + 0] = w0 * c6[0] + w1 * c6[1] + w2 * c6[2];
+          vo[r * 3 + 1] = w0 * c6[1] + w1 * c6[3] + w2 * c6[4];
+          vo[r * 3 + 2] = w0 * c6[2] + w1 * c6[4] + w2 * c6[5];
         }
       }
     }
@@ -971,8 +1007,8 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
   for (int64_t t = d.tchunk_begin[ch] + threadIdx.x; t < e; t += 64) {
     const int64_t p = d.tri_p[t];
     const bool dg = p == d.tri_q[t];
-    const double *Wp = d.W + (size_t)p * 18;
-    const double *Wq = d.W + (size_t)d.tri_q[t] * 18;
+    double Wp[18];
+    expand_W(d.W + (size_t)p * kWStride, Wp);
     const double *ci = d.Cinv + (size_t)d.pair_lm[p] * 6;
     const double *bi = d.b + (size_t)d.pair_lm[p] * 3;
     const double b0 = dg ? bi[0] : 0.0, b1 = dg ? bi[1] : 0.0, b2 = dg ? bi[2] : 0.0;
@@ -985,8 +1021,7 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
       v[r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
       racc[r] += v[r * 3 + 0] * b0 + v[r * 3 + 1] * b1 + v[r * 3 + 2] * b2;
     }
-#pragma unroll
-    for (int k = 0; k < 18; ++k) w[k] = Wq[k];
+    expand_W(d.W + (size_t)d.tri_q[t] * kWStride, w);
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -1107,17 +1142,17 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
 // never materialised) — the same vector sum_j B_ji^T x_j is the cross term of
 // the quadratic model (reference :447-452), so W is read once.
 // One workgroup per chunk of consecutive landmarks (<= kSchurPairs pairs per
-// tile): the W blocks are copied to LDS with contiguous 16-byte loads, lane
-// (pair, c) forms u_c = sum_r W[r][c] x_j[r], then one thread per landmark sums
+// tile): the compact W records are copied to LDS with contiguous 16-byte loads,
+// lane (pair, c) forms u_c = sum_r W[r][c] x_j[r], then one thread per landmark sums
 // its pairs and finishes y, the trial point and the model terms.
 // Dependent-load chain per workgroup: chunk record -> {W, pose indices, the
 // landmarks' own data} -> x_j gather; everything of one level is issued together.
 #define BACKSUB_ISSUE(t0_, np_)                                                 \
   {                                                                             \
-    const double2 *src_ = (const double2 *)(d.W + (size_t)(t0_) * 18);          \
+    const double2 *src_ = (const double2 *)(d.W + (size_t)(t0_) * kWStride);    \
     _Pragma("unroll") for (int k_ = 0; k_ < kBsRW; ++k_) {                      \
       const int t_ = tid + k_ * kBlock;                                         \
-      rw[k_] = (t_ < (np_) * 9) ? src_[t_] : make_double2(0.0, 0.0);            \
+      rw[k_] = (t_ < (np_) * 6) ? src_[t_] : make_double2(0.0, 0.0);            \
     }                                                                           \
     _Pragma("unroll") for (int k_ = 0; k_ < kBsRX; ++k_) {                      \
       const int t_ = tid + k_ * kBlock;                                         \
@@ -1136,7 +1171,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
                    : make_double2(0.0, 0.0);                                    \
     }                                                                           \
   }
-constexpr int kBsRW = (kSchurPairs * 9 + kBlock - 1) / kBlock;
+constexpr int kBsRW = (kSchurPairs * (kWStride / 2) + kBlock - 1) / kBlock;
 constexpr int kBsRX = (kSchurPairs * 3 + kBlock - 1) / kBlock;
 
 // Each workgroup handles kBsChunks consecutive chunks: while chunk k goes
@@ -1151,7 +1186,7 @@ __device__ long long g_bs_dbg[96];
 #define BS_STAMP()
 #endif
 __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
-  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
+  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * kWStride];
   __shared__ __attribute__((aligned(16))) double Xs[kSchurPairs * 6];
   __shared__ double Us[kSchurPairs * 3];
   __shared__ double sm[8];
@@ -1227,7 +1262,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
 #pragma unroll
         for (int q = 0; q < kBsRW; ++q) {
           const int t = tid + q * kBlock;
-          if (t < np * 9) dst[t] = rw[q];
+          if (t < np * 6) dst[t] = rw[q];
         }
         double2 *xd = (double2 *)Xs;
 #pragma unroll
@@ -1252,12 +1287,14 @@ __global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
       BS_STAMP()
       for (int t = tid; t < np * 3; t += kBlock) {
         const int lp = t / 3, c = t - lp * 3;
+        // u_c = sum_r B_ji[r][c] x_j[r] = K[:,c] . (x_t + x_r x X_ij)
         const double *xj = Xs + lp * 6;
-        const double *w = Ws + lp * 18 + c;
-        double u = 0.0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) u = fma(w[r * 3], xj[r], u);
-        Us[t] = u;
+        const double *w = Ws + lp * kWStride;
+        const double X0 = w[9], X1 = w[10], X2 = w[11];
+        const double e0 = xj[0] + (xj[4] * X2 - xj[5] * X1);
+        const double e1 = xj[1] + (xj[5] * X0 - xj[3] * X2);
+        const double e2 = xj[2] + (xj[3] * X1 - xj[4] * X0);
+        Us[t] = fma(w[6 + c], e2, fma(w[3 + c], e1, w[c] * e0));
       }
       BS_STAMP()
       __syncthreads();
