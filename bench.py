@@ -240,12 +240,12 @@ def main():
             # (every array the kernel must read or write, once)
             kbytes = {
                 "k_cost": 32 * n_obs + 24 * M_glob + 96 * n_pose,
-                "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 144 * P +
+                "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 96 * P +
                 144 * M_glob,
                 "k_lin_poses": 32 * O_opt + 24 * M_glob,
-                "k_schur_lds": 144 * P + 72 * M_glob + 4 * T,
+                "k_schur_lds": 96 * P + 72 * M_glob + 4 * T,
                 "k_schur_final": 288 * B,
-                "k_backsub_update": 144 * P + 216 * M_glob,
+                "k_backsub_update": 96 * P + 216 * M_glob,
             }
             tot = {k: v[0] / n_prof for k, v in km.items() if v[1]}
             dense = sum(tot.get(k, 0.0) for k in

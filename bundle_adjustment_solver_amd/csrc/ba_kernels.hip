@@ -1185,7 +1185,7 @@ __device__ long long g_bs_dbg[96];
 #else
 #define BS_STAMP()
 #endif
-__global__ __launch_bounds__(kBlock) void k_backsub_update(DevProblem d) {
+__global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
   __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * kWStride];
   __shared__ __attribute__((aligned(16))) double Xs[kSchurPairs * 6];
   __shared__ double Us[kSchurPairs * 3];
