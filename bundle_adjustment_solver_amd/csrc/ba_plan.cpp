@@ -4,6 +4,7 @@
 #include "ba_dense_sched.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace ba {
@@ -377,10 +378,18 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     std::vector<int32_t> mark(pl.B, -1);               // block -> local slot
     std::vector<int32_t> sup_blocks;
     std::vector<std::pair<int32_t, uint32_t>> loc;
-    // landmarks per super-run: at most kSchurSuperLandmarks, fewer when the
-    // shard is small, so that there are about three workgroups per CU
-    const int sup_cap = (int)std::min<int64_t>(
-        kSchurSuperLandmarks, std::max<int64_t>(kSchurSuperMin, M / kSchurRunTarget));
+    // landmarks per super-run: the kernel runs kSchurRunTarget workgroups at a
+    // time, so the runs are sized to fill a whole number of such rounds (C4:
+    // 500 k landmarks -> 2 rounds of 326 instead of 2.5 rounds of 256), at most
+    // kSchurSuperLandmarks and at least kSchurSuperMin each
+    const int64_t rounds = std::max<int64_t>(
+        1, (M + (int64_t)kSchurRunTarget * kSchurSuperLandmarks - 1) /
+               ((int64_t)kSchurRunTarget * kSchurSuperLandmarks));
+    int sup_cap = (int)std::min<int64_t>(
+        kSchurSuperLandmarks,
+        std::max<int64_t>(kSchurSuperMin,
+                          (M + kSchurRunTarget * rounds - 1) / (kSchurRunTarget * rounds)));
+    if (const char *e = getenv("BA_SUP_CAP")) sup_cap = std::max(1, atoi(e));  // tuning knob
     int i = 0;
     while (i < M) {
       // ---- grow a super-run ----

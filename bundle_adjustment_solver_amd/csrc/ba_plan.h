@@ -44,7 +44,7 @@ constexpr int kSchurLandmarks = 128;  // landmarks per chunk
 static_assert(kSchurPairs <= 256 && kSchurLandmarks <= 256, "triple words hold 8-bit local indices");
 constexpr int kSchurTri = 1024;       // triples per chunk (LDS resident)
 constexpr int kSchurSlots = 128;      // distinct blocks per super-run (>= 2 lanes each)
-constexpr int kSchurSuperLandmarks = 256;  // landmarks per super-run (upper bound)
+constexpr int kSchurSuperLandmarks = 384;  // landmarks per super-run (upper bound)
 constexpr int kSchurSuperMin = 32;         // ... lower bound
 constexpr int kSchurRunTarget = 768;       // super-runs aimed at (3 workgroups x 256 CUs)
 constexpr int kSchurSuperChunks = 64;      // chunks per super-run (descriptor table in LDS)
