@@ -632,7 +632,9 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   __shared__ double cams_s[kCamLds * 16];
   if (LDSCAM) stage_cams(d, cams_s);
   const int lane = threadIdx.x & 63;
-  const int ch = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  // wave-uniform on purpose: the chunk record and the pose (12 doubles) are then
+  // fetched by scalar loads and the pose stays in SGPRs for the whole loop
+  const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
   const bool live = ch < d.n_achunk;
   const int chc = live ? ch : 0;
   // chunk record and control word requested together
@@ -659,9 +661,15 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   double2 cuv = d.pobs_uv[s0c];
   int4 idn = d.pobs_idx[s1c];
   double2 uvn = d.pobs_uv[s1c];
+  // read through the constant address space: uniform address -> s_load, the
+  // pose lives in 24 SGPRs instead of 24 VGPRs
   double Tl[12];
+  {
+    typedef const double __attribute__((address_space(4))) *const_f64_ptr;
+    const_f64_ptr Tc = (const_f64_ptr)(uintptr_t)T;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) Tl[k] = T[k];
+    for (int k = 0; k < 12; ++k) Tl[k] = Tc[k];
+  }
   double XA[3], XB[3];
   {
     const double *Xp = pts + (size_t)id0.z * 3;
