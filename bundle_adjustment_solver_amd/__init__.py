@@ -10,9 +10,10 @@ from .solver import (BaProblem, Camera, FullBundleAdjustmentSolver,  # noqa
                      IterationStatus, OptimizationInfo, Options,
                      PoseOnlyBundleAdjustmentSolver, SolverType, Summary)
 from . import scenes  # noqa
+from . import scene_io  # noqa
 
 __all__ = ["BaProblem", "Camera", "FullBundleAdjustmentSolver",
            "FullBundleAdjustmentSolverRefactor",
            "IterationStatus", "OptimizationInfo", "Options",
            "PoseOnlyBundleAdjustmentSolver", "SolverType", "Summary",
-           "scenes"]
+           "scenes", "scene_io"]

@@ -75,8 +75,38 @@ def pose_only_stereo():
         json.dump(gold, f, indent=0)
 
 
+def bal_fixture():
+    """Small BAL text file with radial distortion (tests/test_scene_io.py,
+    tests/test_gpu_scene_io.py): a mono scene written by save_bal, then every
+    camera gets k1 / k2 and its measurements are distorted accordingly."""
+    from bundle_adjustment_solver_amd import scene_io
+    sc = scenes.synthetic_ba_scene(n_pose=12, n_pt=90, window=5, stereo=False,
+                                   seed=77, n_fixed=2, pixel_sigma=0.3)
+    path = os.path.join(HERE, "bal_small.txt")
+    scene_io.save_bal(path, sc)
+    raw = scene_io.parse_bal(path)
+    rng = np.random.default_rng(5)
+    cams = raw["cameras"]
+    cams[:, 7] = rng.uniform(-0.05, 0.05, cams.shape[0])
+    cams[:, 8] = rng.uniform(-0.01, 0.01, cams.shape[0])
+    ci = raw["cam_index"]
+    p = raw["xy"] / cams[ci, 6:7]
+    r2 = (p * p).sum(axis=1)
+    xy = raw["xy"] * (1.0 + cams[ci, 7] * r2 + cams[ci, 8] * r2 * r2)[:, None]
+    with open(path, "w") as fh:
+        fh.write("%d %d %d\n" % (cams.shape[0], raw["points"].shape[0], xy.shape[0]))
+        for k in range(xy.shape[0]):
+            fh.write("%d %d %.10e %.10e\n" % (ci[k], raw["pt_index"][k], xy[k, 0], xy[k, 1]))
+        for v in cams.reshape(-1):
+            fh.write("%.12e\n" % v)
+        for v in raw["points"].reshape(-1):
+            fh.write("%.12e\n" % v)
+
+
 if __name__ == "__main__":
-    full_ba()
-    pose_only()
-    pose_only_stereo()
+    if "bal" not in sys.argv[1:]:  # `make_golden.py bal` rewrites the BAL file only
+        full_ba()
+        pose_only()
+        pose_only_stereo()
+    bal_fixture()
     print("golden fixtures written")
