@@ -38,6 +38,21 @@ def relerr(a, b):
     return np.abs(a - b).max() / den
 
 
+def pose_errors(P, Q):
+    """SURVEY §8(d) acceptance metrics for (n,12) pose arrays {R row-major, t}:
+    max rotation angle between the two rotations [rad], max |dt| / |t|."""
+    P, Q = np.asarray(P).reshape(-1, 12), np.asarray(Q).reshape(-1, 12)
+    Ra, Rb = P[:, :9].reshape(-1, 3, 3), Q[:, :9].reshape(-1, 3, 3)
+    D = Ra @ np.transpose(Rb, (0, 2, 1))
+    # angle from the skew part (accurate near zero, where arccos is not)
+    w = np.stack([D[:, 2, 1] - D[:, 1, 2], D[:, 0, 2] - D[:, 2, 0],
+                  D[:, 1, 0] - D[:, 0, 1]], axis=1) * 0.5
+    ang = np.arcsin(np.clip(np.linalg.norm(w, axis=1), 0.0, 1.0))
+    dt = np.linalg.norm(P[:, 9:] - Q[:, 9:], axis=1)
+    tn = np.maximum(np.linalg.norm(Q[:, 9:], axis=1), 1e-300)
+    return ang.max(), (dt / tn).max()
+
+
 def blockwise_relerr(a, b):
     """max over leading index of |a-b|_max / |b|_max (blocks with b == 0 must
     be exactly 0 in a)."""
@@ -164,6 +179,10 @@ def test_lm_trajectory(kind, built):
     X, oX = g.get_points()[0], o.get_points()
     assert relerr(P, oP) < RTOL_FINAL * 1e-2
     assert relerr(X, oX) < RTOL_FINAL * 1e-2
+    # the north-star metrics proper: rotation angle [rad], |dt|/|t|, |dX|/|X|
+    ang, dt = pose_errors(P, oP)
+    dX = (np.linalg.norm(X - oX, axis=1) / np.maximum(np.linalg.norm(oX, axis=1), 1e-300)).max()
+    assert ang < RTOL_FINAL * 1e-2 and dt < RTOL_FINAL * 1e-2 and dX < RTOL_FINAL * 1e-2
 
 
 def test_converges_to_truth(built):
