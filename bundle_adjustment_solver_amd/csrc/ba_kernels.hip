@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
 // across super-runs by k_schur_final in run order: deterministic, no atomics.
 constexpr int kSchurRW = (kSchurPairs * (kWStride / 2) + kBlock - 1) / kBlock;
 constexpr int kSchurRC = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
-constexpr int kSchurRT = (kSchurTri + kBlock - 1) / kBlock;
+static_assert(kSchurTri <= 4 * kBlock, "one uint4 of triple words per lane");
 constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
 
 // issue the (contiguous, independent) global loads of one chunk into registers
@@ -754,10 +754,9 @@ constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
       const int t_ = tid + k_ * kBlock;                                       \
       rc[k_] = (t_ < (cd_).nl * 3) ? cs_[t_] : make_double2(0.0, 0.0);        \
     }                                                                         \
-    _Pragma("unroll") for (int k_ = 0; k_ < kSchurRT; ++k_) {                 \
-      const int t_ = tid + k_ * kBlock;                                       \
-      rt[k_] = (t_ < (cd_).nt) ? d.ltri[(cd_).tb + t_] : 0u;                  \
-    }                                                                         \
+    /* the chunk's triple words, four per lane (chunks start 16-byte aligned) */ \
+    rt = (tid * 4 < (cd_).nt) ? ((const uint4 *)(d.ltri + (cd_).tb))[tid]     \
+                              : make_uint4(0u, 0u, 0u, 0u);                   \
     _Pragma("unroll") for (int k_ = 0; k_ < kSchurRB; ++k_) {                 \
       const int t_ = tid + k_ * kBlock;                                       \
       rb[k_] = (t_ < (cd_).nl * 3) ? d.b[(size_t)(cd_).l0 * 3 + t_] : 0.0;    \
@@ -792,7 +791,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   __shared__ __attribute__((aligned(16))) double Vs[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Cs[kSchurLandmarks * 6];
   __shared__ double Bs[kSchurLandmarks * 3];
-  __shared__ uint32_t Ts[kSchurTri];
+  __shared__ __attribute__((aligned(16))) uint32_t Ts[kSchurTri];
   __shared__ uint16_t Sp[kSchurSlots + 1];
   __shared__ uint16_t Pl[kSchurPairs];
   __shared__ DevProblem::ChunkDesc Cdsc[kSchurSuperChunks];
@@ -829,7 +828,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   DevProblem::ChunkDesc cd = d.chunk_desc[sd.chunk_begin];
   if (tid < sd.chunk_end - sd.chunk_begin) Cdsc[tid] = d.chunk_desc[sd.chunk_begin + tid];
   double2 rw[kSchurRW], rc[kSchurRC];
-  uint32_t rt[kSchurRT];
+  uint4 rt;
   double rb[kSchurRB];
   int rpl, rsp;
   SCHUR_PREFETCH(cd)
@@ -852,11 +851,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
         const int t = tid + k * kBlock;
         if (t < cd.nl * 3) cdst[t] = rc[k];
       }
-#pragma unroll
-      for (int k = 0; k < kSchurRT; ++k) {
-        const int t = tid + k * kBlock;
-        if (t < cd.nt) Ts[t] = rt[k];
-      }
+      if (tid * 4 < cd.nt) ((uint4 *)Ts)[tid] = rt;
 #pragma unroll
       for (int k = 0; k < kSchurRB; ++k) {
         const int t = tid + k * kBlock;

@@ -487,6 +487,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
                          [](const auto &x, const auto &y) { return x.first < y.first; });
         Plan::ChunkDesc cd;
         cd.p0 = pbase;
+        while (pl.ltri.size() & 3) pl.ltri.push_back(0u);  // chunks start 16-byte aligned
         cd.tb = (int64_t)pl.ltri.size();
         cd.sp = (int64_t)pl.chunk_sp.size();
         cd.l0 = c0;
@@ -508,6 +509,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       pl.sup_desc.push_back(sd);
       for (int32_t bk : sup_blocks) mark[bk] = -1;
     }
+    for (int k = 0; k < 4; ++k) pl.ltri.push_back(0u);  // the last chunk's 16-byte loads stay inside
     // per-block contribution lists (ascending super-run = ascending slot id)
     pl.blk_contrib_ptr.assign(pl.B + 1, 0);
     for (auto &c2 : contrib) pl.blk_contrib_ptr[c2.first + 1]++;
