@@ -441,6 +441,7 @@ int ba_finalize(ba_handle *h) {
       h->upload(&d.tchunk_begin, pl.tchunk_begin) || h->upload(&d.tchunk_end, pl.tchunk_end) ||
       h->upload(&d.sblk_tchunk_ptr, pl.sblk_tchunk_ptr) ||
       h->upload(&d.ltri, pl.ltri) || h->upload(&d.chunk_sp, pl.chunk_sp) ||
+      h->upload(&d.sup_lane, pl.sup_lane) ||
       h->upload(&d.blk_contrib_ptr, pl.blk_contrib_ptr) || h->upload(&d.contrib_slot, pl.contrib_slot))
     return -1;
   d.n_sup = (int)pl.sup_desc.size();

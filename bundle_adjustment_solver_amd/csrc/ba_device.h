@@ -86,6 +86,7 @@ struct DevProblem {
     int32_t l0, nl, np, nt;
   };
   SupDesc *sup_desc;
+  uint32_t *sup_lane;  // n_sup*256: lane -> (slot, half, position, lanes per half) of k_schur_lds
   ChunkDesc *chunk_desc;
   uint16_t *chunk_sp;
   uint32_t *ltri;

@@ -797,26 +797,22 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   __shared__ DevProblem::ChunkDesc Cdsc[kSchurSuperChunks];
   const int tid = threadIdx.x;
   const DevProblem::SupDesc sd = d.sup_desc[blockIdx.x];
+  const uint32_t lane_word = d.sup_lane[(size_t)blockIdx.x * kBlock + tid];
   const int ns = sd.ns;
   const int done = d.ctrl->done;
   BA_KEEP_S(sd.chunk_begin);
   BA_KEEP_S(done);
   if (done) return;
-  // slots are dealt to the four waves (at most spw per wave, never straddling
-  // one); every slot gets tps = 64 / spw lanes (even, at most 32).  A lane owns
-  // HALF a slot: rows 3h..3h+2 of the 6x6 block (18 accumulators + 3 of the
-  // rhs), so that the kernel fits three workgroups per CU; the tps/2 lanes of
-  // one half share the slot's triples and are summed at the end by a guarded
-  // shuffle-down tree.
-  const int spw = (ns + 3) >> 2;
-  const int tps = spw <= 2 ? 32 : ((64 / spw) & ~1);
-  const int lane = tid & 63;
-  const int sl = lane / tps, sub = lane - sl * tps;
-  const int h = sub & 1, sub2 = sub >> 1, tps2 = tps >> 1;
-  // slot ids follow the block order, i.e. the position along the run: dealing
-  // them round-robin keeps all four waves busy in every chunk
-  const int slot = sl * 4 + (tid >> 6);
-  const bool owner = sl < spw && slot < ns;
+  // Lane table of the run (host: deal_lanes in ba_plan.cpp): every slot owns an
+  // even number of lanes inside one wave, in proportion to its triple count.
+  // A lane owns HALF a slot: rows 3h..3h+2 of the 6x6 block (18 accumulators +
+  // 3 of the rhs), so that the kernel fits three workgroups per CU; the tps2
+  // lanes of one half share the slot's triples and are summed at the end by a
+  // guarded shuffle-down tree.
+  const int slot = (int)(lane_word & 0xffu);
+  const int h = (int)((lane_word >> 8) & 1u), sub2 = (int)((lane_word >> 9) & 0x1fu);
+  const int tps2 = (int)((lane_word >> 14) & 0x3fu);
+  const bool owner = slot < ns;
   double acc[18], racc[3];
 #pragma unroll
   for (int k = 0; k < 18; ++k) acc[k] = 0.0;

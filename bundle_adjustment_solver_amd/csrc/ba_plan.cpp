@@ -54,6 +54,23 @@ void locality_order(const PlanInput &in,
   for (int q = 0; q < in.n_pt; ++q) order[bucket[first_pose[q]]++] = q;
 }
 
+// Landmarks per Schur super-run for a shard of M optimised landmarks: the kernel
+// runs kSchurRunTarget workgroups at a time, so the runs are sized to fill a
+// whole number of such rounds (C4: 500 k landmarks -> 2 rounds of 326 instead
+// of 2.5 rounds of 256), at most kSchurSuperLandmarks and at least
+// kSchurSuperMin each.
+int schur_run_cap(int64_t M) {
+  const int64_t rounds = std::max<int64_t>(
+      1, (M + (int64_t)kSchurRunTarget * kSchurSuperLandmarks - 1) /
+             ((int64_t)kSchurRunTarget * kSchurSuperLandmarks));
+  int cap = (int)std::min<int64_t>(
+      kSchurSuperLandmarks,
+      std::max<int64_t>(kSchurSuperMin,
+                        (M + kSchurRunTarget * rounds - 1) / (kSchurRunTarget * rounds)));
+  if (const char *e = getenv("BA_SUP_CAP")) cap = std::max(1, atoi(e));  // tuning knob
+  return cap;
+}
+
 void assign_owner(const PlanInput &in, const std::vector<int32_t> &order,
                   const std::vector<int64_t> &obs_count,
                   std::vector<int32_t> &owner) {
@@ -96,6 +113,55 @@ void make_chunks(const std::vector<int64_t> &ptr, int n_seg, int chunk,
 }
 
 }  // namespace
+
+// Lane table of one Schur super-run (k_schur_lds: 4 waves x 64 lanes).  Slot s
+// gets an even number of lanes n_s in [2, 32], contiguous inside ONE wave, in
+// proportion to its triple count; lane word = slot | h << 8 | sub2 << 9 |
+// (n_s / 2) << 14, 0xff = idle lane.  Waves: longest-processing-time first on
+// the triple counts; lanes inside a wave: repeatedly +2 to the slot with the
+// most triples per lane.  Deterministic (ties by slot id).
+void deal_lanes(const std::vector<int64_t> &tcount, std::vector<uint32_t> &out) {
+  const int ns = (int)tcount.size();
+  std::vector<int> ord(ns);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return tcount[a] > tcount[b]; });
+  std::vector<int> wave_of(ns, 0), nl(ns, 2);
+  int64_t load[4] = {0, 0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0};
+  for (int s : ord) {
+    int w = -1;
+    for (int c = 0; c < 4; ++c)
+      if (cnt[c] < 32 && (w < 0 || load[c] < load[w])) w = c;
+    wave_of[s] = w;
+    load[w] += tcount[s];
+    cnt[w]++;
+  }
+  const size_t base = out.size();
+  out.resize(base + 256, 0xffu);
+  for (int w = 0; w < 4; ++w) {
+    int free_lanes = 64 - 2 * cnt[w];
+    while (free_lanes >= 2) {
+      int best = -1;
+      for (int s = 0; s < ns; ++s) {
+        if (wave_of[s] != w || nl[s] >= 32) continue;
+        // tcount[s] / nl[s] > tcount[best] / nl[best], in integers
+        if (best < 0 || tcount[s] * nl[best] > tcount[best] * nl[s]) best = s;
+      }
+      if (best < 0 || tcount[best] == 0) break;
+      nl[best] += 2;
+      free_lanes -= 2;
+    }
+    int lane = 0;
+    for (int s = 0; s < ns; ++s) {
+      if (wave_of[s] != w) continue;
+      for (int sub = 0; sub < nl[s]; ++sub)
+        out[base + 64 * w + lane + sub] =
+            (uint32_t)s | ((uint32_t)(sub & 1) << 8) | ((uint32_t)(sub >> 1) << 9) |
+            ((uint32_t)(nl[s] >> 1) << 14);
+      lane += nl[s];
+    }
+  }
+}
 
 void partition_points(const PlanInput &in, std::vector<int32_t> &owner) {
   std::vector<int32_t> piu, pui, jou;
@@ -150,6 +216,23 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     }
   }
   pl.M = (int)pl.pt_user_of_int.size();
+  // Interleave inside windows of one Schur super-run: position p of a window
+  // takes the landmark p would have had in residue-class order (k = r, r + S,
+  // r + 2S, ...), so that every chunk of consecutive landmarks samples the
+  // WHOLE window and touches the run's S blocks in the run's proportions
+  // (the lanes of the Schur kernel are dealt to the blocks in those proportions).
+  if (!(getenv("BA_NO_INTERLEAVE") && getenv("BA_NO_INTERLEAVE")[0] == '1')) {
+    const int W = schur_run_cap(pl.M);
+    std::vector<int32_t> tmp;
+    for (int base = 0; base < pl.M; base += W) {
+      const int n = std::min(W, pl.M - base);
+      tmp.clear();
+      for (int r = 0; r < kSchurInterleave; ++r)
+        for (int k = r; k < n; k += kSchurInterleave) tmp.push_back(pl.pt_user_of_int[base + k]);
+      for (int k = 0; k < n; ++k) pl.pt_user_of_int[base + k] = tmp[k];
+    }
+    for (int k = 0; k < pl.M; ++k) pl.pt_int_of_user[pl.pt_user_of_int[k]] = k;
+  }
   for (int idx = 0; idx < in.n_pt; ++idx) {
     const int q = order[idx];
     if (pl.owner[q] == in.rank && in.pt_fixed[q]) {
@@ -378,18 +461,9 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     std::vector<int32_t> mark(pl.B, -1);               // block -> local slot
     std::vector<int32_t> sup_blocks;
     std::vector<std::pair<int32_t, uint32_t>> loc;
-    // landmarks per super-run: the kernel runs kSchurRunTarget workgroups at a
-    // time, so the runs are sized to fill a whole number of such rounds (C4:
-    // 500 k landmarks -> 2 rounds of 326 instead of 2.5 rounds of 256), at most
-    // kSchurSuperLandmarks and at least kSchurSuperMin each
-    const int64_t rounds = std::max<int64_t>(
-        1, (M + (int64_t)kSchurRunTarget * kSchurSuperLandmarks - 1) /
-               ((int64_t)kSchurRunTarget * kSchurSuperLandmarks));
-    int sup_cap = (int)std::min<int64_t>(
-        kSchurSuperLandmarks,
-        std::max<int64_t>(kSchurSuperMin,
-                          (M + kSchurRunTarget * rounds - 1) / (kSchurRunTarget * rounds)));
-    if (const char *e = getenv("BA_SUP_CAP")) sup_cap = std::max(1, atoi(e));  // tuning knob
+    std::vector<int64_t> tcount;  // triples per slot of the current run
+    pl.sup_lane.clear();
+    const int sup_cap = schur_run_cap(M);
     int i = 0;
     while (i < M) {
       // ---- grow a super-run ----
@@ -461,6 +535,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         pl.slot_blk.push_back(order[s]);
       }
       // ---- chunks ----
+      tcount.assign(ns, 0);
       int l = i0;
       while (l < i1) {
         const int c0 = l;
@@ -500,13 +575,17 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           while (t < loc.size() && loc[t].first < s) ++t;
           pl.chunk_sp.push_back((uint16_t)t);
         }
-        for (auto &e : loc) pl.ltri.push_back(e.second);
+        for (auto &e : loc) {
+          pl.ltri.push_back(e.second);
+          tcount[e.first]++;
+        }
         pl.chunk_desc.push_back(cd);
       }
       sd.chunk_end = (int32_t)pl.chunk_desc.size();
       if (sd.chunk_end - sd.chunk_begin > kSchurSuperChunks)
         return "internal: super-run exceeds kSchurSuperChunks chunks";
       pl.sup_desc.push_back(sd);
+      deal_lanes(tcount, pl.sup_lane);
       for (int32_t bk : sup_blocks) mark[bk] = -1;
     }
     for (int k = 0; k < 4; ++k) pl.ltri.push_back(0u);  // the last chunk's 16-byte loads stay inside

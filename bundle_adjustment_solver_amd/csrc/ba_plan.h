@@ -47,6 +47,7 @@ constexpr int kSchurSlots = 128;      // distinct blocks per super-run (>= 2 lan
 constexpr int kSchurSuperLandmarks = 384;  // landmarks per super-run (upper bound)
 constexpr int kSchurSuperMin = 32;         // ... lower bound
 constexpr int kSchurRunTarget = 768;       // super-runs aimed at (3 workgroups x 256 CUs)
+constexpr int kSchurInterleave = 32;       // residue classes of the in-window landmark interleave
 constexpr int kSchurSuperChunks = 64;      // chunks per super-run (descriptor table in LDS)
 
 struct Plan {
@@ -110,6 +111,7 @@ struct Plan {
     int32_t l0, nl, np, nt;              // landmarks, pairs, triples
   };
   std::vector<SupDesc> sup_desc;
+  std::vector<uint32_t> sup_lane;        // 256 lane words per super-run (deal_lanes)
   std::vector<ChunkDesc> chunk_desc;
   std::vector<uint16_t> chunk_sp;        // per chunk: ns+1 slot offsets
   std::vector<int32_t> slot_blk;         // block of each slot
