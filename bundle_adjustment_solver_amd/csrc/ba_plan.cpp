@@ -4,6 +4,7 @@
 #include "ba_dense_sched.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 
@@ -462,6 +463,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     std::vector<int32_t> sup_blocks;
     std::vector<std::pair<int32_t, uint32_t>> loc;
     std::vector<int64_t> tcount;  // triples per slot of the current run
+    double sum_max = 0, sum_ideal = 0, sum_mean_active = 0;  // BA_PLAN_STATS
+    long n_ch = 0;
     pl.sup_lane.clear();
     const int sup_cap = schur_run_cap(M);
     int i = 0;
@@ -586,8 +589,32 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         return "internal: super-run exceeds kSchurSuperChunks chunks";
       pl.sup_desc.push_back(sd);
       deal_lanes(tcount, pl.sup_lane);
+      if (getenv("BA_PLAN_STATS")) {  // balance of the triple loop (developer knob)
+        const uint32_t *lw = &pl.sup_lane[pl.sup_lane.size() - 256];
+        std::vector<int> tps2(ns, 1);
+        for (int q = 0; q < 256; ++q)
+          if ((lw[q] & 0xffu) < (uint32_t)ns) tps2[lw[q] & 0xffu] = (lw[q] >> 14) & 0x3f;
+        for (int c = sd.chunk_begin; c < sd.chunk_end; ++c) {
+          const uint16_t *sp = &pl.chunk_sp[pl.chunk_desc[c].sp];
+          int mx = 0, tot = 0, act = 0;
+          for (int q = 0; q < ns; ++q) {
+            const int cnt = sp[q + 1] - sp[q];
+            tot += cnt;
+            act += cnt > 0;
+            mx = std::max(mx, (cnt + tps2[q] - 1) / tps2[q]);
+          }
+          sum_max += mx;
+          sum_ideal += tot * 2.0 / 256.0;
+          sum_mean_active += act;
+          ++n_ch;
+        }
+      }
       for (int32_t bk : sup_blocks) mark[bk] = -1;
     }
+    if (n_ch > 0)
+      fprintf(stderr, "[plan] chunks %ld: triple-loop iterations per chunk: busiest lane %.2f, ideal %.2f; "
+                      "active slots %.1f\n",
+              n_ch, sum_max / n_ch, sum_ideal / n_ch, sum_mean_active / n_ch);
     for (int k = 0; k < 4; ++k) pl.ltri.push_back(0u);  // the last chunk's 16-byte loads stay inside
     // per-block contribution lists (ascending super-run = ascending slot id)
     pl.blk_contrib_ptr.assign(pl.B + 1, 0);
