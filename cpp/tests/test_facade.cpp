@@ -6,11 +6,13 @@
 // pose-only facade against the oracle.  Exit code 0 = pass.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <unordered_map>
 #include <vector>
 
 #include "core/full_bundle_adjustment_solver.h"
+#include "utility/bal_io.h"
 #include "core/full_bundle_adjustment_solver_refactor.h"
 #include "core/pose_only_bundle_adjustment_solver.h"
 #include "eigen3/Eigen/Dense"
@@ -304,6 +306,30 @@ int main() {
                 ss.GetOptimizationInfoList().size(), errs);
     EXPECT(errs < 1e-3f, "stereo pose-only did not recover the true pose");
     EXPECT(ml.size() == 10000 && mr.size() == 10000, "stereo mask sizes");
+  }
+  // ---------------- BAL scene file through the facade ----------------
+  {
+    const char *env = std::getenv("BA_TEST_BAL");
+    const std::string path = env ? env : "tests/golden/bal_small.txt";
+    visual_navigation::scene_io::BalProblem bal;
+    std::string err;
+    EXPECT(visual_navigation::scene_io::LoadBal(path, &bal, &err), "LoadBal(%s): %s", path.c_str(), err.c_str());
+    EXPECT(!visual_navigation::scene_io::LoadBal(path, &bal, &err, /*undistort=*/false),
+           "a distorted file must be refused without undistortion");
+    EXPECT(visual_navigation::scene_io::LoadBal(path, &bal, &err), "LoadBal again");
+    if (!bal.poses.empty()) {
+      EXPECT(bal.poses.size() == 12 && bal.points.size() == 90 && bal.observations.size() == 450, "fixture sizes");
+      FullBundleAdjustmentSolver bs;
+      visual_navigation::scene_io::AddToSolver(&bal, &bs, 2);
+      Options bo;
+      bo.iteration_handle.max_num_iterations = 20;
+      Summary bsum;
+      EXPECT(bs.Solve(bo, &bsum), "BAL solve");
+      const auto &br = bsum.GetOptimizationInfoList();
+      EXPECT(!br.empty() && br.back().cost < 0.1 * br.front().cost, "BAL problem did not converge");
+      if (!br.empty())
+        std::printf("BAL fixture: cost %.4e -> %.4e in %zu iterations\n", br.front().cost, br.back().cost, br.size());
+    }
   }
   std::printf(g_fail ? "C++ FACADE TEST FAILED (%d)\n" : "C++ FACADE TEST PASSED\n", g_fail);
   return g_fail ? 1 : 0;
