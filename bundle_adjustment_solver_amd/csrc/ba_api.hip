@@ -556,6 +556,7 @@ int ba_finalize(ba_handle *h) {
          h->dalloc(&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * nb * nb)))
       return -1;
     dd.col_x = d.col_x;
+    dd.read_env();
     HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
     // tiles (re)initialised per iteration: factor pattern + diagonal + rhs row
     std::vector<int> ztI, ztJ;
@@ -1041,6 +1042,7 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   }
   double *dL = nullptr, *dD = nullptr, *dx = nullptr;
   ba::DenseDev dd;
+  dd.read_env();
   auto up = [&](int **p, const std::vector<int> &v) -> int {
     HIP_TRY(hipMalloc((void **)p, std::max<size_t>(1, v.size()) * sizeof(int)));
     if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));

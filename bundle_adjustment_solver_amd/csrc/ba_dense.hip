@@ -184,15 +184,14 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   // measured no faster than the three-kernel path (886 vs 876 us per LM
   // iteration) because tiles that survive many levels collect long pending
   // lists, which their single consumer then gathers serially.
-  const char *fz = getenv("BA_DENSE_FUSED");
-  const bool fused = sc.fused_ok && dd.f_desc && fz && fz[0] == '1';
+  // (the knobs are read when the schedule is uploaded, not once per LM iteration)
+  const bool fused = sc.fused_ok && dd.f_desc && dd.want_fused;
   // BA_DENSE_SPLIT=1: separate diagonal and TRSM launches (the TRSM then spreads
   // over one workgroup per row tile: better for dense patterns with many row
   // tiles per column); default: the tile's workgroup also solves its row tiles
-  const char *sp = getenv("BA_DENSE_SPLIT");
   // (all row tiles of a column must fit the prefetched passes: 4 passes x
   //  (4 waves / (nb/16)) tiles)
-  const bool split = (sp && sp[0] == '1') || !dd.row_desc || sc.max_rows > 4 * (4 / (sc.nb / 16));
+  const bool split = dd.want_split || !dd.row_desc || sc.max_rows > 4 * (4 / (sc.nb / 16));
   (void)row_limit;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -216,6 +217,13 @@ struct DenseDev {
   double *cbuf = nullptr;  // n_contrib contribution tiles (NB x NB, column-major)
   int *col_x = nullptr;   // npad: column -> index into x (6*pose + r) or -1
   double *xc = nullptr;   // npad: solution in column order
+  // BA_DENSE_FUSED / BA_DENSE_SPLIT as found when the schedule was uploaded
+  bool want_fused = false, want_split = false;
+  void read_env() {
+    const char *f = getenv("BA_DENSE_FUSED"), *s = getenv("BA_DENSE_SPLIT");
+    want_fused = f && f[0] == '1';
+    want_split = s && s[0] == '1';
+  }
 };
 struct DenseSchedule;
 void launch_dense_solve(const DevProblem &d, const DenseSchedule &sc,
