@@ -1223,6 +1223,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
   }
   __syncthreads();  // recs
   BS_STAMP()
+  double est_acc = 0.0, nrm_acc = 0.0;
   for (int k = 0; k < nk; ++k) {
     const int64_t pb = r_pb, pe = r_pb + r_np;
     const int l0 = r_l0, nl = r_nl;
@@ -1341,13 +1342,16 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
       nrm = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
     }
     BS_STAMP()
-    block_sum2(est, nrm, sm);
-    if (tid == 0) {
-      d.lm_part[2 * (c0 + k) + 0] = est;
-      d.lm_part[2 * (c0 + k) + 1] = nrm;
-    }
-    BS_STAMP()
+    est_acc += est;  // a thread owns at most one landmark per chunk: fixed order
+    nrm_acc += nrm;
   }
+  // one pair of partial sums per workgroup (k_scalars adds them in block order)
+  block_sum2(est_acc, nrm_acc, sm);
+  if (tid == 0) {
+    d.lm_part[2 * blockIdx.x + 0] = est_acc;
+    d.lm_part[2 * blockIdx.x + 1] = nrm_acc;
+  }
+  BS_STAMP()
 #ifdef BA_BS_DBG
   if (bs_on) for (int q = 0; q < 96; ++q) g_bs_dbg[q] = q < bs_n ? bs_s[q] : 0;
 #endif
@@ -1452,17 +1456,23 @@ constexpr int kScalBlock = 1024;
 __global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode) {
   if (d.ctrl->done) return;
   double c = 0.0, e = 0.0, n = 0.0, pe = 0.0, pn = 0.0;
-#pragma unroll 1
-  for (int k = threadIdx.x; k < kCostGrid; k += kScalBlock) c += d.cost_part[k];
+  {  // both rounds of the cost partials requested at once
+    static_assert(kCostGrid <= 2 * kScalBlock, "two loads per thread");
+    const int k1 = threadIdx.x + kScalBlock;
+    const double c0 = d.cost_part[threadIdx.x < kCostGrid ? threadIdx.x : 0];
+    const double c1 = d.cost_part[k1 < kCostGrid ? k1 : 0];
+    c = (threadIdx.x < kCostGrid ? c0 : 0.0) + (k1 < kCostGrid ? c1 : 0.0);
+  }
   if (mode >= 1) {
     const double2 *lp = (const double2 *)d.lm_part;
     // eight independent loads in flight per thread
-    for (int k0 = threadIdx.x; k0 < d.n_bchunk; k0 += 8 * kScalBlock) {
+    const int n_lp = (d.n_bchunk + kBsChunks - 1) / kBsChunks;  // one entry per backsub workgroup
+    for (int k0 = threadIdx.x; k0 < n_lp; k0 += 8 * kScalBlock) {
       double2 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int k = k0 + u * kScalBlock;
-        v[u] = k < d.n_bchunk ? lp[k] : make_double2(0.0, 0.0);
+        v[u] = k < n_lp ? lp[k] : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
