@@ -1,0 +1,147 @@
+// Host-only invariants of the work plan (csrc/ba_plan.cpp), compiled with g++ by
+// tests/test_plan_invariants.py.  Scene: every landmark is seen by `win`
+// consecutive poses in `n_cam` cameras (the C2..C4 structure), plus a few
+// landmarks seen by many poses and a few never observed.
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+
+#include "ba_plan.h"
+
+static int g_fail = 0;
+#define CHECK(cond, ...)                                  \
+  do {                                                    \
+    if (!(cond)) {                                        \
+      if (g_fail < 20) {                                  \
+        std::printf("FAIL line %d: ", __LINE__);          \
+        std::printf(__VA_ARGS__);                         \
+        std::printf("\n");                                \
+      }                                                   \
+      ++g_fail;                                           \
+    }                                                     \
+  } while (0)
+
+int main(int argc, char **argv) {
+  const int n_pose = argc > 1 ? atoi(argv[1]) : 120, n_pt = argc > 2 ? atoi(argv[2]) : 30000;
+  const int win = argc > 3 ? atoi(argv[3]) : 5, n_cam = argc > 4 ? atoi(argv[4]) : 2;
+  std::vector<uint8_t> pf(n_pose, 0), qf(n_pt, 0);
+  for (int k = 0; k < 3; ++k) pf[k] = 1;
+  for (int q = 0; q < n_pt; q += 97) qf[q] = 1;
+  std::vector<int32_t> oc, op, oq;
+  std::vector<double> uv;
+  for (int q = 0; q < n_pt; ++q) {
+    if (q % 1013 == 5) continue;  // never observed
+    int j0 = (int)((long long)q * (n_pose - win + 1) / n_pt), w = win;
+    if (q % 4001 == 7) { j0 = 0; w = n_pose; }  // seen by every pose
+    for (int j = j0; j < j0 + w; ++j)
+      for (int c = 0; c < n_cam; ++c) { oc.push_back(c); op.push_back(j); oq.push_back(q); uv.push_back(q); uv.push_back(j); }
+  }
+  ba::PlanInput in;
+  in.n_cam = n_cam; in.n_pose = n_pose; in.pose_fixed = pf.data(); in.n_pt = n_pt; in.pt_fixed = qf.data();
+  in.n_obs = (int64_t)oc.size(); in.obs_cam = oc.data(); in.obs_pose = op.data(); in.obs_pt = oq.data(); in.obs_uv = uv.data();
+  ba::Plan pl;
+  const std::string err = ba::build_plan(in, pl);
+  CHECK(err.empty(), "build_plan: %s", err.c_str());
+  if (!err.empty()) return 1;
+
+  // ---- landmark order is a permutation; optimised first, then fixed ----
+  std::vector<int> seen(n_pt, 0);
+  CHECK((int)pl.pt_user_of_int.size() == n_pt, "all points owned at world 1");
+  for (int k = 0; k < (int)pl.pt_user_of_int.size(); ++k) {
+    const int q = pl.pt_user_of_int[k];
+    CHECK(q >= 0 && q < n_pt && !seen[q], "duplicate / bad point %d", q);
+    seen[q] = 1;
+    CHECK(pl.pt_int_of_user[q] == k, "inverse map broken at %d", k);
+    CHECK((k < pl.M) == (qf[q] == 0), "optimised landmarks must come first (k=%d)", k);
+  }
+  // ---- observation list: landmark-major, every pair id in range, last writer only ----
+  CHECK(pl.n_obs == in.n_obs, "observation count");
+  for (int i = 0; i < pl.M; ++i) {
+    std::set<int> poses;
+    for (int64_t s = pl.lm_obs_ptr[i]; s < pl.lm_obs_ptr[i + 1]; ++s) {
+      CHECK(pl.obs_idx[4 * s + 2] == i, "obs %lld not under its landmark", (long long)s);
+      const int pid = pl.obs_idx[4 * s + 3];
+      if (pid >= 0) {
+        CHECK(pid >= pl.lm_pair_ptr[i] && pid < pl.lm_pair_ptr[i + 1], "pair id out of the landmark's range");
+        CHECK(poses.insert(pl.pair_pose[pid]).second, "two writers for one pair");
+        CHECK(pl.pair_pose[pid] == pl.obs_idx[4 * s + 1] && pl.pair_lm[pid] == i, "pair (pose, landmark) mismatch");
+      }
+    }
+    CHECK((int64_t)poses.size() == pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i], "every pair has exactly one writer");
+  }
+  // ---- Schur super-runs ----
+  CHECK(pl.sup_lane.size() == pl.sup_desc.size() * 256, "lane table size");
+  std::vector<int> covered(pl.M, 0);
+  int64_t triples = 0;
+  for (size_t r = 0; r < pl.sup_desc.size(); ++r) {
+    const auto &sd = pl.sup_desc[r];
+    CHECK(sd.ns >= 1 && sd.ns <= ba::kSchurSlots, "slots per run");
+    CHECK(sd.chunk_end - sd.chunk_begin >= 1 && sd.chunk_end - sd.chunk_begin <= ba::kSchurSuperChunks, "chunks per run");
+    // lane table: every slot owns an even number (2..32) of consecutive lanes of ONE wave
+    std::vector<int> first(sd.ns, -1), count(sd.ns, 0);
+    for (int lane = 0; lane < 256; ++lane) {
+      const uint32_t w = pl.sup_lane[r * 256 + lane];
+      const int slot = w & 0xff;
+      if (slot == 0xff) continue;
+      CHECK(slot < sd.ns, "lane word names slot %d of %d", slot, sd.ns);
+      if (slot >= sd.ns) continue;
+      const int h = (w >> 8) & 1, sub2 = (w >> 9) & 0x1f, tps2 = (w >> 14) & 0x3f;
+      if (first[slot] < 0) first[slot] = lane;
+      const int sub = lane - first[slot];
+      CHECK(sub == 2 * sub2 + h, "lane layout inside a slot (run %zu lane %d)", r, lane);
+      CHECK(sub2 < tps2 && tps2 >= 1 && tps2 <= 16, "sub2 / tps2 range");
+      CHECK(first[slot] / 64 == lane / 64, "slot straddles two waves");
+      count[slot]++;
+    }
+    for (int s = 0; s < sd.ns; ++s) {
+      CHECK(count[s] >= 2 && count[s] % 2 == 0 && count[s] <= 32, "slot %d has %d lanes", s, count[s]);
+      const uint32_t w = pl.sup_lane[r * 256 + (first[s] < 0 ? 0 : first[s])];
+      CHECK((int)((w >> 14) & 0x3f) * 2 == count[s], "tps2 field does not match the lane count");
+    }
+    for (int c = sd.chunk_begin; c < sd.chunk_end; ++c) {
+      const auto &cd = pl.chunk_desc[c];
+      CHECK(cd.np >= 1 && cd.np <= ba::kSchurPairs && cd.nl >= 1 && cd.nl <= ba::kSchurLandmarks &&
+                cd.nt >= 1 && cd.nt <= ba::kSchurTri, "chunk limits");
+      CHECK((cd.tb & 3) == 0 && cd.tb + cd.nt + 3 < (int64_t)pl.ltri.size(), "16-byte triple loads stay inside");
+      CHECK(cd.p0 == pl.lm_pair_ptr[cd.l0], "chunk pair base");
+      for (int l = cd.l0; l < cd.l0 + cd.nl; ++l) covered[l]++;
+      const uint16_t *sp = &pl.chunk_sp[cd.sp];
+      CHECK(sp[0] == 0 && sp[sd.ns] == cd.nt, "slot offsets span the chunk's triples");
+      for (int s = 0; s < sd.ns; ++s) {
+        CHECK(sp[s] <= sp[s + 1], "slot offsets ascend");
+        for (int t = sp[s]; t < sp[s + 1]; ++t) {
+          const uint32_t w = pl.ltri[cd.tb + t];
+          const int p = w >> 16, q = w & 0xff, lm = (w >> 8) & 0xff;
+          CHECK(p < cd.np && q < cd.np && p <= q && lm < cd.nl, "triple word fields");
+          CHECK(pl.pair_lm[cd.p0 + p] == cd.l0 + lm && pl.pair_lm[cd.p0 + q] == cd.l0 + lm, "triple's landmark");
+          const int jb = pl.pair_pose[cd.p0 + p], kb = pl.pair_pose[cd.p0 + q];
+          const int blk = pl.slot_blk[sd.s0 + s];
+          CHECK(pl.sblk_j[blk] == std::min(jb, kb) && pl.sblk_k[blk] == std::max(jb, kb), "triple filed under the wrong block");
+        }
+      }
+      triples += cd.nt;
+    }
+  }
+  // every landmark with pairs is covered exactly once, by a super-run or by the big-landmark list
+  int64_t big_triples = 0;
+  for (int i = 0; i < pl.M; ++i) {
+    const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
+    if (d == 0) continue;
+    const bool big = covered[i] == 0;
+    CHECK(covered[i] <= 1, "landmark %d in %d chunks", i, covered[i]);
+    if (big) big_triples += d * (d + 1) / 2;
+  }
+  CHECK(triples + big_triples == pl.T, "triples: %lld in runs + %lld big != %lld", (long long)triples,
+        (long long)big_triples, (long long)pl.T);
+  CHECK((int64_t)pl.tri_p.size() == big_triples, "global triple list holds exactly the big landmarks");
+  // back-substitution chunks tile the landmarks
+  CHECK(pl.bchunk_lm.front() == 0 && pl.bchunk_lm.back() == pl.M, "backsub chunks cover [0, M)");
+  for (size_t c = 0; c + 1 < pl.bchunk_lm.size(); ++c)
+    CHECK(pl.bchunk_lm[c] < pl.bchunk_lm[c + 1] && pl.bchunk_lm[c + 1] - pl.bchunk_lm[c] <= ba::kSchurLandmarks,
+          "backsub chunk size");
+  std::printf("plan: M=%d P=%lld runs=%zu chunks=%zu triples=%lld (+%lld big)  %s\n", pl.M, (long long)pl.P,
+              pl.sup_desc.size(), pl.chunk_desc.size(), (long long)triples, (long long)big_triples,
+              g_fail ? "FAILED" : "OK");
+  return g_fail ? 1 : 0;
+}
