@@ -172,7 +172,8 @@ int ba_get_A(ba_handle *h, double *A36, double *a6);
  * point index; entries of points owned by other shards are left untouched */
 int ba_get_C(ba_handle *h, double *C9, double *b3);
 int ba_get_Cinv(ba_handle *h, double *Cinv9, double *Cinvb3);
-/* pairs (global i_opt, j_opt) in internal order with W = B_ji (6x3) */
+/* pairs (global i_opt, j_opt) in internal order with W = B_ji (6x3, row-major; the
+ * device keeps it compact as {K, X_ij} and this call expands it) */
 int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18);
 /* reduced camera system, (6N)^2 row-major, and rhs, in opt-pose order */
 int ba_get_S(ba_handle *h, double *S, double *rhs);
