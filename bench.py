@@ -250,7 +250,7 @@ def main():
             tot = {k: v[0] / n_prof for k, v in km.items() if v[1]}
             dense = sum(tot.get(k, 0.0) for k in
                         ("k_chol_diag", "k_chol_trsm", "k_chol_diag_trsm", "k_chol_update",
-                         "k_chol_back", "k_chol_level"))
+                         "k_chol_back", "k_chol_level", "k_chol_tail"))
             dom = max(kbytes, key=lambda k: tot.get(k, 0.0))
             dom_ms = tot[dom] / km[dom][1] * n_prof   # average launch duration
             ach = kbytes[dom] / (dom_ms * 1e-3) / 1e9

@@ -980,7 +980,7 @@ const char *ba_kernel_name(int id) {
   static const char *names[ba::K_COUNT] = {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
       "k_schur_lds", "k_schur_partial", "k_schur_final", "k_scatter",
-      "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_chol_diag_trsm", "k_backsub_update",
+      "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_chol_diag_trsm", "k_chol_tail", "k_backsub_update",
       "k_pose_update", "k_scalars", "k_control"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
 }

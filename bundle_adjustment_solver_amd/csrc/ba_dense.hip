@@ -133,6 +133,150 @@ extern "C" int ba_debug_read_dense(long long *out) {
 }
 #endif
 
+
+// ---- the last levels in ONE workgroup ---------------------------------------
+// The level schedule ends with levels of 3, 2, 1 tiles, each of which costs a
+// full launch + global round-trip chain (~27 us) for almost no work.  The
+// trailing block of the dense image (the tiles of the last levels are its last
+// columns: positions are in elimination order) is at that point the Schur
+// complement of everything eliminated before, with its right-hand side in the
+// rhs row.  This kernel takes the whole block (<= kTailCols columns + the 16-row
+// rhs block) into LDS, factors it by left-looking 16-column panels exactly like
+// factor_tile_lds (MFMA panel update and TRSM, wave 0 factors the 16x16
+// diagonal tiles), forward-substitutes the rhs as one more row tile, and runs
+// the block back substitution in the same launch; only x leaves.
+constexpr int kTailCols = 96;
+constexpr int kTailLS = kTailCols + 16 + 1;  // column stride of the LDS image (rows + rhs block + pad)
+constexpr int kTailES = 17;
+// NPt = 16-column panels of the block (compile time: the panel loops unroll and
+// their LDS reads pipeline; with run-time bounds the kernel was twice as slow).
+template <int NPt>
+__global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int npad, int c0,
+                                                   double *xc, double *x,
+                                                   const int *__restrict__ col_x, const int *done) {
+  constexpr int nbt = 16 * NPt;
+  static_assert(nbt <= kTailCols, "tail block does not fit the LDS image");
+  __shared__ double Lb[kTailCols * kTailLS];             // Lb[c*LS + r], r < nbt: matrix, r >= nbt: rhs block
+  __shared__ double Eb[kTailCols / 16][16 * kTailES];    // Eb[p][k*ES + c] = E_pp[k][c], E_pp = L_pp^-T
+  __shared__ double xs[kTailCols];
+  constexpr int LS = kTailLS, ES = kTailES;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  constexpr int nr = nbt + 16;  // rows of the LDS image; row tile NPt is the rhs block
+  // the whole block is requested before anything waits (one load per
+  // iteration followed by its LDS store would pay ~40 memory latencies in a row)
+  constexpr int kLd = (nbt * nr + 255) / 256;
+  double lv[kLd];
+#pragma unroll
+  for (int k = 0; k < kLd; ++k) {
+    const int e = tid + 256 * k;
+    const int c = e / nr, rr = e - c * nr;
+    const int row = rr < nbt ? c0 + rr : npad + (rr - nbt);
+    lv[k] = (e < nbt * nr && rr >= c) ? L[(size_t)(c0 + c) * ld + row] : 0.0;
+  }
+  if (done && *done) return;
+#pragma unroll
+  for (int k = 0; k < kLd; ++k) {
+    const int e = tid + 256 * k;
+    const int c = e / nr, rr = e - c * nr;
+    if (e < nbt * nr) Lb[c * LS + rr] = lv[k];
+  }
+  for (int e = tid; e < (kTailCols / 16) * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NPt; ++p) {
+    // (1) left-looking update of panel p: tile (ti,p) -= sum_kt L(ti,kt) L(p,kt)^T, ti = p .. NPt
+    if (p > 0) {
+#pragma unroll
+      for (int ti = p + wv; ti <= NPt; ti += 4) {
+        v4f64 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr];
+#pragma unroll
+        for (int kc = 0; kc < 16 * p; kc += 4) {
+          const double a = -Lb[(kc + lk) * LS + 16 * p + lr];
+          const double b = Lb[(kc + lk) * LS + 16 * ti + lr];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr] = acc[g];
+      }
+      __syncthreads();
+    }
+    // (2) factor the diagonal tile (wave 0)
+    if (wv == 0) {
+      const int r = lr, q = lk;
+      double g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * j + q;
+        g[j] = (r >= c) ? Lb[(16 * p + c) * LS + 16 * p + r] : 0.0;
+      }
+      tile16_potrf_inv(g, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * j + q;
+        if (r >= c) Lb[(16 * p + c) * LS + 16 * p + r] = g[j];
+        if (r < c) Eb[p][r * ES + c] = g[j];
+        if (r == c) Eb[p][r * ES + c] = (g[j] > 0.0) ? 1.0 / g[j] : 0.0;
+      }
+    }
+    __syncthreads();
+    // (3) TRSM of the tiles below (incl. the rhs block): X = T * E_pp
+#pragma unroll
+    for (int ti = p + 1 + wv; ti <= NPt; ti += 4) {
+      v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double a = Eb[p][(lk + 4 * g) * ES + lr];
+        const double b = Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      // all reads of this tile precede the writes within the wave
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr] = acc[g];
+    }
+    __syncthreads();
+  }
+  // (4) L^T x = y by block back substitution (wave 0): y is row 0 of the rhs block,
+  //     x_p = E_pp (y_p - sum_{u>p} L_up^T x_u)
+  if (wv == 0) {
+    const int i = lr, q = lk;
+#pragma unroll
+    for (int p = NPt - 1; p >= 0; --p) {
+      double acc = 0.0;
+#pragma unroll
+      for (int u = p + 1; u < NPt; ++u)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = 16 * u + 4 * q + rr;
+          acc += Lb[(16 * p + i) * LS + row] * xs[row];
+        }
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      const double wvv = Lb[(16 * p + i) * LS + nbt] - acc;
+      double px = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c2 = 4 * q + cc;
+        px += Eb[p][i * ES + c2] * __shfl(wvv, c2, 64);
+      }
+      px += __shfl_xor(px, 16, 64);
+      px += __shfl_xor(px, 32, 64);
+      if (q == 0) xs[16 * p + i] = px;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  __syncthreads();
+  if (tid < nbt) {
+    xc[c0 + tid] = xs[tid];
+    const int xi = col_x[c0 + tid];
+    if (xi >= 0) x[xi] = xs[tid];
+  }
+}
+
 }  // namespace
 
 void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
@@ -148,7 +292,7 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
 // target-centric update launch; then one backward launch per level.
 // NS = nb32 or nb64 (the kernels of the schedule's tile order).
 #define BA_DENSE_RUN(NS)                                                                    \
-  for (int l = 0; l < sc.nlev; ++l) {                                                       \
+  for (int l = 0; l < sc.nlev - tail_levels; ++l) {                                         \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     if (fused) {                                                                            \
       BA_LAUNCH(K_CHOL_LEVEL, NS::k_chol_level, dim3(nt), dim3(256), s, L, ld, npad, t0,    \
@@ -170,7 +314,13 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
       BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(ng), dim3(256), s, L, ld, tg0,       \
                 dd.tgt_desc, dd.src_t, done);                                               \
   }                                                                                         \
-  for (int l = sc.nlev - 1; l >= 0; --l) {                                                  \
+  if (tail_cols == 64)                                                                      \
+    BA_LAUNCH(K_CHOL_TAIL, k_chol_tail<4>, dim3(1), dim3(256), s, L, ld, npad, tail_c0,     \
+              dd.xc, x, dd.col_x, done);                                                    \
+  if (tail_cols == 96)                                                                      \
+    BA_LAUNCH(K_CHOL_TAIL, k_chol_tail<6>, dim3(1), dim3(256), s, L, ld, npad, tail_c0,     \
+              dd.xc, x, dd.col_x, done);                                                    \
+  for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back, dim3(nt), dim3(256), s, L, ld, npad, t0,        \
               dd.back_desc, dd.rows, Ldiag, dd.xc, x, dd.col_x, done);                      \
@@ -193,6 +343,19 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   //  (4 waves / (nb/16)) tiles)
   const bool split = dd.want_split || !dd.row_desc || sc.max_rows > 4 * (4 / (sc.nb / 16));
   (void)row_limit;
+  // the last levels (at least two, together at most kTailCols columns) are
+  // handed to k_chol_tail: one launch instead of three per level (BA_DENSE_TAIL=0: off)
+  int tail_levels = 0, tail_cols = 0;
+  if (dd.want_tail && !fused) {
+    for (int l = sc.nlev - 1; l >= 0; --l) {
+      const int cols = (sc.lev_ptr[l + 1] - sc.lev_ptr[l]) * sc.nb;
+      if (tail_cols + cols > kTailCols) break;
+      tail_cols += cols;
+      ++tail_levels;
+    }
+    if (tail_levels < 2 || (tail_cols != 64 && tail_cols != 96)) tail_levels = tail_cols = 0;
+  }
+  const int tail_c0 = tail_levels > 0 ? sc.lev_ptr[sc.nlev - tail_levels] * sc.nb : 0;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

@@ -150,7 +150,7 @@ constexpr int kSlotStride = 42;  // 6x6 block of B Cinv B^T + 6 of B Cinv b
 enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
   K_SCHUR_LDS, K_SCHUR_PARTIAL, K_SCHUR_FINAL, K_SCATTER,
-  K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_CHOL_DIAG_TRSM, K_BACKSUB_UPDATE,
+  K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_CHOL_DIAG_TRSM, K_CHOL_TAIL, K_BACKSUB_UPDATE,
   K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_COUNT
 };
 struct KernelTimer {
@@ -217,12 +217,13 @@ struct DenseDev {
   double *cbuf = nullptr;  // n_contrib contribution tiles (NB x NB, column-major)
   int *col_x = nullptr;   // npad: column -> index into x (6*pose + r) or -1
   double *xc = nullptr;   // npad: solution in column order
-  // BA_DENSE_FUSED / BA_DENSE_SPLIT as found when the schedule was uploaded
-  bool want_fused = false, want_split = false;
+  // BA_DENSE_FUSED / BA_DENSE_SPLIT / BA_DENSE_TAIL as found when the schedule was uploaded
+  bool want_fused = false, want_split = false, want_tail = true;
   void read_env() {
-    const char *f = getenv("BA_DENSE_FUSED"), *s = getenv("BA_DENSE_SPLIT");
+    const char *f = getenv("BA_DENSE_FUSED"), *s = getenv("BA_DENSE_SPLIT"), *t = getenv("BA_DENSE_TAIL");
     want_fused = f && f[0] == '1';
     want_split = s && s[0] == '1';
+    want_tail = !(t && t[0] == '0');
   }
 };
 struct DenseSchedule;
