@@ -313,6 +313,38 @@ def test_fused_level_factorisation_matches_default_path(built):
     assert np.abs(xs[0] - xs[1]).max() <= 1e-9 * np.abs(xs[0]).max()
 
 
+def test_tail_workgroup_matches_the_level_path(built):
+    """k_chol_tail (last levels of the dense solve in one workgroup, default)
+    against BA_DENSE_TAIL=0 (every level by its own launches): same x on a
+    chain scene (tail of 2 + 1 tiles), on a 7-pose scene whose whole reduced
+    system is the tail, and for a dense SPD system."""
+    import os
+    for sc in (scenes.synthetic_ba_scene(60, 2500, 5, True, seed=21),
+               scenes.synthetic_ba_scene(12, 300, 5, False, seed=22)):
+        pr = scenes.scaled_problem(sc)
+        xs = []
+        for flag in ("0", "1"):
+            os.environ["BA_DENSE_TAIL"] = flag
+            try:
+                p = make_gpu(pr)
+                p.stage_linearize(10.0, 1.0)
+                p.stage_schur()
+                p.stage_solve_reduced()
+                xs.append(p.get_xy()[0].copy())
+            finally:
+                os.environ.pop("BA_DENSE_TAIL", None)
+        assert np.abs(xs[0]).max() > 0
+        assert np.abs(xs[0] - xs[1]).max() <= 1e-9 * np.abs(xs[0]).max()
+    rng = np.random.default_rng(4)
+    n = 150
+    Q = rng.standard_normal((n, 40))
+    A = Q @ Q.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    g = BaProblem(0)
+    x, _ = g.dense_spd_solve(A, b)
+    assert np.abs(A @ x - b).max() < 1e-10 * np.abs(b).max() * n
+
+
 def _compare_solve(pr, iters=6, tol_cost=1e-7, tol_par=1e-6):
     g, o = make_gpu(pr), O.Oracle(pr)
     lam = 3.0
