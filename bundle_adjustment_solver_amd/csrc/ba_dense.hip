@@ -150,12 +150,13 @@ constexpr int kTailLS = kTailCols + 16 + 1;  // column stride of the LDS image (
 constexpr int kTailES = 17;
 // NPt = 16-column panels of the block (compile time: the panel loops unroll and
 // their LDS reads pipeline; with run-time bounds the kernel was twice as slow).
-template <int NPt>
+template <int NPt, bool PAIR>
 __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int npad, int c0,
                                                    double *xc, double *x,
                                                    const int *__restrict__ col_x, const int *done) {
   constexpr int nbt = 16 * NPt;
   static_assert(nbt <= kTailCols, "tail block does not fit the LDS image");
+  static_assert(!PAIR || NPt >= 4, "a paired first level has two 32-column tiles");
   __shared__ double Lb[kTailCols * kTailLS];             // Lb[c*LS + r], r < nbt: matrix, r >= nbt: rhs block
   __shared__ double Eb[kTailCols / 16][16 * kTailES];    // Eb[p][k*ES + c] = E_pp[k][c], E_pp = L_pp^-T
   __shared__ double xs[kTailCols];
@@ -183,17 +184,28 @@ __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int 
   }
   for (int e = tid; e < (kTailCols / 16) * 16 * ES; e += 256) (&Eb[0][0])[e] = 0.0;
   __syncthreads();
+  // Macro-steps.  PAIR: the first level of the block has TWO 32-column tiles
+  // (panels 0,1 and 2,3).  Tiles of one level are independent (the tile between
+  // them is structurally zero), so their panels are processed side by side:
+  // {0,2}, {1,3}, then 4, 5 — four sequential 16x16 factorisations instead of six.
+  constexpr int NG = PAIR ? NPt - 2 : NPt;
 #pragma unroll
-  for (int p = 0; p < NPt; ++p) {
-    // (1) left-looking update of panel p: tile (ti,p) -= sum_kt L(ti,kt) L(p,kt)^T, ti = p .. NPt
-    if (p > 0) {
-#pragma unroll
-      for (int ti = p + wv; ti <= NPt; ti += 4) {
+  for (int m = 0; m < NG; ++m) {
+    const int p0 = PAIR ? (m < 2 ? m : m + 2) : m;
+    const bool two = PAIR && m < 2;
+    // this wave's panel: waves 0,1 -> p0 and waves 2,3 -> p0 + 2 in a paired step
+    const int p = (two && wv >= 2) ? p0 + 2 : p0;
+    const int w2 = two ? (wv & 1) : wv, nw = two ? 2 : 4;
+    // columns that can contribute to panel p: from its own tile on in a paired
+    // step (the other tile's columns are zero in these rows), else all earlier ones
+    const int kc0 = two ? 32 * (p >> 1) : 0;
+    // (1) left-looking update: tile (ti,p) -= sum_kt L(ti,kt) L(p,kt)^T, ti = p .. NPt
+    if (m > 0) {
+      for (int ti = p + w2; ti <= NPt; ti += nw) {
         v4f64 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = Lb[(16 * p + lk + 4 * g) * LS + 16 * ti + lr];
-#pragma unroll
-        for (int kc = 0; kc < 16 * p; kc += 4) {
+        for (int kc = kc0; kc < 16 * p; kc += 4) {
           const double a = -Lb[(kc + lk) * LS + 16 * p + lr];
           const double b = Lb[(kc + lk) * LS + 16 * ti + lr];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
@@ -203,8 +215,8 @@ __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int 
       }
       __syncthreads();
     }
-    // (2) factor the diagonal tile (wave 0)
-    if (wv == 0) {
+    // (2) factor the diagonal tile(s): wave 0 (and wave 2 for the second panel of a paired step)
+    if (wv == 0 || (two && wv == 2)) {
       const int r = lr, q = lk;
       double g[4];
 #pragma unroll
@@ -223,8 +235,7 @@ __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int 
     }
     __syncthreads();
     // (3) TRSM of the tiles below (incl. the rhs block): X = T * E_pp
-#pragma unroll
-    for (int ti = p + 1 + wv; ti <= NPt; ti += 4) {
+    for (int ti = p + 1 + w2; ti <= NPt; ti += nw) {
       v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -315,11 +326,14 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
                 dd.tgt_desc, dd.src_t, done);                                               \
   }                                                                                         \
   if (tail_cols == 64)                                                                      \
-    BA_LAUNCH(K_CHOL_TAIL, k_chol_tail<4>, dim3(1), dim3(256), s, L, ld, npad, tail_c0,     \
-              dd.xc, x, dd.col_x, done);                                                    \
-  if (tail_cols == 96)                                                                      \
-    BA_LAUNCH(K_CHOL_TAIL, k_chol_tail<6>, dim3(1), dim3(256), s, L, ld, npad, tail_c0,     \
-              dd.xc, x, dd.col_x, done);                                                    \
+    BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<4, false>), dim3(1), dim3(256), s, L, ld, npad,     \
+              tail_c0, dd.xc, x, dd.col_x, done);                                           \
+  if (tail_cols == 96 && !tail_pair)                                                        \
+    BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<6, false>), dim3(1), dim3(256), s, L, ld, npad,     \
+              tail_c0, dd.xc, x, dd.col_x, done);                                           \
+  if (tail_cols == 96 && tail_pair)                                                         \
+    BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<6, true>), dim3(1), dim3(256), s, L, ld, npad,      \
+              tail_c0, dd.xc, x, dd.col_x, done);                                           \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back, dim3(nt), dim3(256), s, L, ld, npad, t0,        \
@@ -356,6 +370,10 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
     if (tail_levels < 2 || (tail_cols != 64 && tail_cols != 96)) tail_levels = tail_cols = 0;
   }
   const int tail_c0 = tail_levels > 0 ? sc.lev_ptr[sc.nlev - tail_levels] * sc.nb : 0;
+  // two (independent) tiles in the first level of the block: their panels go side by side
+  const bool tail_pair = tail_levels > 0 && sc.nb == 32 &&
+                         sc.lev_ptr[sc.nlev - tail_levels + 1] - sc.lev_ptr[sc.nlev - tail_levels] == 2;
+  (void)tail_pair;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {
