@@ -413,7 +413,7 @@ __device__ long long g_ll_dbg[32];
 #define LL_STAMP()
 #endif
 template <bool LDSCAM>
-__global__ __launch_bounds__(kBlock) void k_lin_landmarks(DevProblem d) {
+__global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
 #ifdef BA_LL_DBG
   __shared__ long long ll_s[32];
   const bool ll_on = blockIdx.x == 9000 && threadIdx.x == 0;

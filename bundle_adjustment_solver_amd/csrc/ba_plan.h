@@ -40,7 +40,7 @@ constexpr int kPoseChunkMin = 256, kPoseChunkMax = 4096;
 constexpr int kPoseWaveTarget = 8192;
 constexpr int kTriChunk = 256;     // triples per Schur partial-sum item
 constexpr int kSchurPairs = 128;      // pairs staged in LDS per chunk
-constexpr int kSchurLandmarks = 128;  // landmarks per chunk
+constexpr int kSchurLandmarks = 64;  // landmarks per chunk
 static_assert(kSchurPairs <= 256 && kSchurLandmarks <= 256, "triple words hold 8-bit local indices");
 constexpr int kSchurTri = 1024;       // triples per chunk (LDS resident)
 constexpr int kSchurSlots = 128;      // distinct blocks per super-run (>= 2 lanes each)
