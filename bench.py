@@ -242,7 +242,7 @@ def main():
                 "k_cost": 32 * n_obs + 24 * M_glob + 96 * n_pose,
                 "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 96 * P +
                 144 * M_glob,
-                "k_lin_poses": 32 * O_opt + 24 * M_glob,
+                "k_lin_poses": 24 * O_opt + 24 * M_glob,
                 "k_schur_lds": 96 * P + 72 * M_glob + 4 * T,
                 "k_schur_final": 288 * B,
                 "k_backsub_update": 96 * P + 216 * M_glob,

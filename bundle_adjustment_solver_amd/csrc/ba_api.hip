@@ -428,7 +428,7 @@ int ba_finalize(ba_handle *h) {
   if (h->dalloc(&d.pobs_idx, (size_t)pl.n_pobs)) return -1;
   if (h->dalloc(&d.pobs_uv, (size_t)pl.n_pobs)) return -1;
   if (pl.n_pobs > 0) {
-    HIP_TRY(hipMemcpy(d.pobs_idx, pl.pobs_idx.data(), (size_t)pl.n_pobs * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.pobs_idx, pl.pobs_idx.data(), (size_t)pl.n_pobs * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d.pobs_uv, pl.pobs_uv.data(), (size_t)pl.n_pobs * 16, hipMemcpyHostToDevice));
   }
   if (h->upload(&d.lm_obs_ptr, pl.lm_obs_ptr) || h->upload(&d.lm_pair_ptr, pl.lm_pair_ptr) ||

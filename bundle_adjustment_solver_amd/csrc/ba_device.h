@@ -64,7 +64,7 @@ struct DevProblem {
   int32_t *pair_pose;
   int32_t *pair_lm;
   // pose-major observations
-  int4 *pobs_idx;
+  int2 *pobs_idx;   // {camera, point}
   double2 *pobs_uv;
   int32_t *achunk_pose;
   int64_t *achunk_begin, *achunk_end;

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
 // gathered point of s+64 are in flight while s is processed.
 #define LINP_STEP(XC, XN)                                                       \
   {                                                                             \
-    const double *Xp_ = pts + (size_t)idn.z * 3;                                \
+    const double *Xp_ = pts + (size_t)idn.y * 3;                                \
     _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) XN[k_] = Xp_[k_];          \
     const int ncam_ = idn.x;                                                    \
     const double2 nuv_ = uvn;                                                   \
@@ -657,9 +657,9 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   const double *T = d.poses[buf] + (size_t)j * 12;
   int64_t s = b + lane;
   const int64_t s0c = s < e ? s : e - 1, s1c = s + 64 < e ? s + 64 : e - 1;
-  const int4 id0 = d.pobs_idx[s0c];
+  const int2 id0 = d.pobs_idx[s0c];
   double2 cuv = d.pobs_uv[s0c];
-  int4 idn = d.pobs_idx[s1c];
+  int2 idn = d.pobs_idx[s1c];
   double2 uvn = d.pobs_uv[s1c];
   // read through the constant address space: uniform address -> s_load, the
   // pose lives in 24 SGPRs instead of 24 VGPRs
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   }
   double XA[3], XB[3];
   {
-    const double *Xp = pts + (size_t)id0.z * 3;
+    const double *Xp = pts + (size_t)id0.y * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) XA[k] = Xp[k];
   }

@@ -318,16 +318,14 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     for (int64_t s : psel) pl.pose_obs_ptr[pl.obs_idx[4 * s + 1] + 1]++;
     for (int j = 0; j < N; ++j) pl.pose_obs_ptr[j + 1] += pl.pose_obs_ptr[j];
     pl.n_pobs = (int64_t)psel.size();
-    pl.pobs_idx.resize((size_t)pl.n_pobs * 4);
+    pl.pobs_idx.resize((size_t)pl.n_pobs * 2);
     pl.pobs_uv.resize((size_t)pl.n_pobs * 2);
     std::vector<int64_t> cur(pl.pose_obs_ptr.begin(), pl.pose_obs_ptr.end() - 1);
     for (int64_t s : psel) {
       const int j = pl.obs_idx[4 * s + 1];
       const int64_t d = cur[j]++;
-      pl.pobs_idx[4 * d + 0] = pl.obs_idx[4 * s + 0];
-      pl.pobs_idx[4 * d + 1] = j;
-      pl.pobs_idx[4 * d + 2] = pl.obs_idx[4 * s + 2];
-      pl.pobs_idx[4 * d + 3] = 0;
+      pl.pobs_idx[2 * d + 0] = pl.obs_idx[4 * s + 0];  // camera
+      pl.pobs_idx[2 * d + 1] = pl.obs_idx[4 * s + 2];  // point (the pose is the list's own)
       pl.pobs_uv[2 * d + 0] = pl.obs_uv[2 * s + 0];
       pl.pobs_uv[2 * d + 1] = pl.obs_uv[2 * s + 1];
     }

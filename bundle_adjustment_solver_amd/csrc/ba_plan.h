@@ -84,7 +84,7 @@ struct Plan {
   std::vector<int32_t> pair_pose;    // P (internal pose, < N)
   std::vector<int32_t> pair_lm;      // P (internal point, < M)
   // ---- pose-major observations (optimisable poses only) ----
-  std::vector<int32_t> pobs_idx;  // n_pobs*4: cam, pose_int, pt_int, 0
+  std::vector<int32_t> pobs_idx;  // n_pobs*2: cam, pt_int (pose-major copy: the pose is implied)
   std::vector<double> pobs_uv;    // n_pobs*2
   std::vector<int64_t> pose_obs_ptr;     // N+1
   std::vector<int32_t> achunk_pose;      // per A/a work item
