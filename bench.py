@@ -239,7 +239,7 @@ def main():
             # algorithmic HBM bytes per launch of each streaming kernel
             # (every array the kernel must read or write, once)
             kbytes = {
-                "k_cost": 32 * n_obs + 24 * M_glob + 96 * n_pose,
+                "k_cost": 24 * n_obs + 24 * M_glob + 96 * n_pose,
                 "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 96 * P +
                 144 * M_glob,
                 "k_lin_poses": 24 * O_opt + 24 * M_glob,

@@ -425,6 +425,14 @@ int ba_finalize(ba_handle *h) {
     HIP_TRY(hipMemcpy(d.obs_idx, pl.obs_idx.data(), (size_t)pl.n_obs * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d.obs_uv, pl.obs_uv.data(), (size_t)pl.n_obs * 16, hipMemcpyHostToDevice));
   }
+  // slim landmark-major record for the cost kernel (no pair id, 8 bytes)
+  d.obs_cp = nullptr;
+  if (pl.n_cam < 65536 && pl.n_pose < 65536 && pl.n_obs > 0) {
+    std::vector<int2> cp((size_t)pl.n_obs);
+    for (int64_t k = 0; k < pl.n_obs; ++k)
+      cp[k] = make_int2(pl.obs_idx[4 * k + 0] | (pl.obs_idx[4 * k + 1] << 16), pl.obs_idx[4 * k + 2]);
+    if (h->upload(&d.obs_cp, cp)) return -1;
+  }
   if (h->dalloc(&d.pobs_idx, (size_t)pl.n_pobs)) return -1;
   if (h->dalloc(&d.pobs_uv, (size_t)pl.n_pobs)) return -1;
   if (pl.n_pobs > 0) {

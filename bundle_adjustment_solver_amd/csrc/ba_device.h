@@ -65,6 +65,7 @@ struct DevProblem {
   int32_t *pair_lm;
   // pose-major observations
   int2 *pobs_idx;   // {camera, point}
+  int2 *obs_cp;     // n_obs {camera | pose << 16, point} for k_cost, or null (>= 65536 cameras / poses)
   double2 *pobs_uv;
   int32_t *achunk_pose;
   int64_t *achunk_begin, *achunk_end;

@@ -314,6 +314,32 @@ __device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
   o[0] = b00; o[1] = b01; o[2] = b02; o[3] = b11; o[4] = b12; o[5] = b22;
 }
 
+// Observation record as the cost kernel reads it: {camera, pose, point}.  SLIM:
+// the 8-byte copy obs_cp = {camera | pose << 16, point} (problems with fewer
+// than 65 536 cameras and poses) instead of the 16-byte record that also carries
+// the pair id.  The fields are decoded where they are USED, one step after the
+// load: arithmetic on a just-loaded prefetch value would wait for it.
+template <bool SLIM>
+struct ObsRec;
+template <>
+struct ObsRec<true> {
+  int2 v;
+  __device__ __forceinline__ int cam() const { return v.x & 0xffff; }
+  __device__ __forceinline__ int pose() const { return (int)((unsigned)v.x >> 16); }
+  __device__ __forceinline__ int pt() const { return v.y; }
+  __device__ __forceinline__ void load(const DevProblem &d, int64_t s) { v = d.obs_cp[s]; }
+  __device__ __forceinline__ void clear() { v = make_int2(0, 0); }
+};
+template <>
+struct ObsRec<false> {
+  int4 v;
+  __device__ __forceinline__ int cam() const { return v.x; }
+  __device__ __forceinline__ int pose() const { return v.y; }
+  __device__ __forceinline__ int pt() const { return v.z; }
+  __device__ __forceinline__ void load(const DevProblem &d, int64_t s) { v = d.obs_idx[s]; }
+  __device__ __forceinline__ void clear() { v = make_int4(0, 0, 0, 0); }
+};
+
 // --------------------------------------------------------------------------
 // cost: sum over observations of ||r||  (reference :381-433)
 // --------------------------------------------------------------------------
@@ -325,17 +351,17 @@ __device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
 #define COST_STEP(TC, XC, TN, XN)                                               \
   {                                                                             \
     /* gathers of the next observation (record arrived one step ago) */         \
-    const double *Tp_ = poses + (size_t)idn.y * 12;                             \
-    const double *Xp_ = pts + (size_t)idn.z * 3;                                \
+    const double *Tp_ = poses + (size_t)idn.pose() * 12;                        \
+    const double *Xp_ = pts + (size_t)idn.pt() * 3;                             \
     _Pragma("unroll") for (int k_ = 0; k_ < 12; ++k_) TN[k_] = Tp_[k_];         \
     _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) XN[k_] = Xp_[k_];          \
-    const int ncam_ = idn.x;                                                    \
+    const int ncam_ = idn.cam();                                                \
     const double2 nuv_ = uvn;                                                   \
     /* record two strides ahead, into the registers just read (clamped, not  */ \
     /* conditional: a join after a conditional load waits for it)            */ \
     {                                                                           \
       const int64_t s2_ = s + 2 * stride < d.n_obs ? s + 2 * stride : d.n_obs - 1; \
-      idn = d.obs_idx[s2_];                                                     \
+      idn.load(d, s2_);                                                         \
       uvn = d.obs_uv[s2_];                                                      \
     }                                                                           \
     ObsGeom g_;                                                                 \
@@ -348,7 +374,7 @@ __device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
     cuv = nuv_;                                                                 \
   }
 
-template <bool LDSCAM>
+template <bool LDSCAM, bool SLIM>
 __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
   __shared__ double sm[4];
   __shared__ double cams_s[kCamLds * 16];
@@ -356,10 +382,11 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   // first record issued before the control word is needed
-  int4 id0 = make_int4(0, 0, 0, 0);
+  ObsRec<SLIM> id0;
+  id0.clear();
   double2 cuv = make_double2(0.0, 0.0);
   if (s < d.n_obs) {
-    id0 = d.obs_idx[s];
+    id0.load(d, s);
     cuv = d.obs_uv[s];
   }
   if (d.ctrl->done) return;
@@ -368,18 +395,19 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
   const double *__restrict__ pts = d.pts[buf];
   // past-the-end prefetches are clamped to the last record: harmless gathers
   const int64_t s1 = s + stride < d.n_obs ? s + stride : d.n_obs - 1;
-  int4 idn = d.obs_idx[s1];
+  ObsRec<SLIM> idn;
+  idn.load(d, s1);
   double2 uvn = d.obs_uv[s1];
   double TA[12], XA[3], TB[12], XB[3];
   {
-    const double *Tp = poses + (size_t)id0.y * 12;
-    const double *Xp = pts + (size_t)id0.z * 3;
+    const double *Tp = poses + (size_t)id0.pose() * 12;
+    const double *Xp = pts + (size_t)id0.pt() * 3;
 #pragma unroll
     for (int k = 0; k < 12; ++k) TA[k] = Tp[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) XA[k] = Xp[k];
   }
-  int ccam = id0.x;
+  int ccam = id0.cam();
   double acc = 0.0;
   __syncthreads();  // cams_s
   while (s < d.n_obs) {
@@ -1608,10 +1636,16 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 }  // namespace
 
 void launch_cost(const DevProblem &d, int sel, hipStream_t s) {
-  if (d.n_cam <= kCamLds)
-    BA_LAUNCH(K_COST, k_cost<true>, dim3(kCostGrid), dim3(kBlock), s, d, sel);
-  else
-    BA_LAUNCH(K_COST, k_cost<false>, dim3(kCostGrid), dim3(kBlock), s, d, sel);
+  const bool lds = d.n_cam <= kCamLds, slim = d.obs_cp != nullptr;
+  if (lds && slim) {
+    BA_LAUNCH(K_COST, (k_cost<true, true>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+  } else if (lds) {
+    BA_LAUNCH(K_COST, (k_cost<true, false>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+  } else if (slim) {
+    BA_LAUNCH(K_COST, (k_cost<false, true>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+  } else {
+    BA_LAUNCH(K_COST, (k_cost<false, false>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+  }
 }
 
 void launch_linearize(const DevProblem &d, hipStream_t s) {
