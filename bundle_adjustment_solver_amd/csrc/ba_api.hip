@@ -427,7 +427,8 @@ int ba_finalize(ba_handle *h) {
   }
   // slim landmark-major record for the cost kernel (no pair id, 8 bytes)
   d.obs_cp = nullptr;
-  if (pl.n_cam < 65536 && pl.n_pose < 65536 && pl.n_obs > 0) {
+  const char *wide = getenv("BA_COST_WIDE");  // test knob: keep k_cost on the 16-byte records
+  if (pl.n_cam < 65536 && pl.n_pose < 65536 && pl.n_obs > 0 && !(wide && wide[0] == '1')) {
     std::vector<int2> cp((size_t)pl.n_obs);
     for (int64_t k = 0; k < pl.n_obs; ++k)
       cp[k] = make_int2(pl.obs_idx[4 * k + 0] | (pl.obs_idx[4 * k + 1] << 16), pl.obs_idx[4 * k + 2]);

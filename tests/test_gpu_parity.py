@@ -313,6 +313,25 @@ def test_fused_level_factorisation_matches_default_path(built):
     assert np.abs(xs[0] - xs[1]).max() <= 1e-9 * np.abs(xs[0]).max()
 
 
+def test_cost_kernel_record_variants(built):
+    """k_cost on the 8-byte {camera|pose, point} records (default) and on the
+    16-byte records it falls back to for >= 65 536 cameras / poses
+    (BA_COST_WIDE=1 forces them): same cost, equal to the oracle's."""
+    import os
+    sc = scenes.synthetic_ba_scene(30, 1200, 5, True, seed=23)
+    pr = scenes.scaled_problem(sc)
+    ref = O.Oracle(pr).cost()
+    costs = []
+    for flag in ("0", "1"):
+        os.environ["BA_COST_WIDE"] = flag
+        try:
+            costs.append(make_gpu(pr).stage_cost())
+        finally:
+            os.environ.pop("BA_COST_WIDE", None)
+    assert costs[0] == costs[1]
+    assert relerr(costs[0], ref) < 1e-12
+
+
 def test_tail_workgroup_matches_the_level_path(built):
     """k_chol_tail (last levels of the dense solve in one workgroup, default)
     against BA_DENSE_TAIL=0 (every level by its own launches): same x on a
