@@ -86,15 +86,10 @@ struct ba_handle {
   ba::DenseDev ddev;
   std::vector<int> pose_col_h;
   // pose-only scratch (grown on demand, reused across calls)
-  int po_cap_n = 0, po_cap_it = 0;
-  float *po_uvr = nullptr, *po_camr = nullptr, *po_part = nullptr;
-  int *po_gsync = nullptr;
-  uint8_t *po_maskr = nullptr;
-  int po_cap_nr = 0;
-  float *po_X = nullptr, *po_uv = nullptr, *po_T = nullptr, *po_dbg = nullptr;
-  uint8_t *po_mask = nullptr;
-  ba::PoIter *po_iters = nullptr;
-  int *po_meta = nullptr;
+  // pose-only: one device buffer + its pinned host mirror (po_run), barrier scratch
+  uint8_t *po_dev = nullptr, *po_host = nullptr;
+  size_t po_cap = 0;
+  float *po_part = nullptr;
 
   template <class T>
   int dalloc(T **p, size_t n) {
@@ -120,6 +115,11 @@ struct ba_handle {
   void free_device() {
     for (void *p : allocs) (void)hipFree(p);
     allocs.clear();
+    if (po_dev) (void)hipFree(po_dev);
+    if (po_host) (void)hipHostFree(po_host);
+    po_dev = po_host = nullptr;
+    po_cap = 0;
+    po_part = nullptr;  // was in `allocs`
     finalized = false;
   }
 };
@@ -1094,6 +1094,106 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   return 0;
 }
 
+}  // extern "C" (reopened below)
+
+// One call = one H2D copy, one kernel, one D2H copy, all through ONE pinned
+// staging buffer that mirrors ONE device buffer (ten small pageable copies
+// cost more than the kernel at 10 k points):
+//   [X | uv | uv_right | right camera | T | mask | mask_right | barrier words ]  <- H2D
+//                                     [ T | mask | mask_right | barrier words | meta | iters | debug poses ]  <- D2H
+namespace {
+struct PoLayout {
+  size_t X, uv, uvr, camr, T, mask, maskr, gsw, h2d_end, meta, iters, dbg, end;
+};
+PoLayout po_layout(int n, int icap, bool stereo) {
+  auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  PoLayout L;
+  size_t o = 0;
+  L.X = o;      o = al(o + (size_t)n * 3 * sizeof(float));
+  L.uv = o;     o = al(o + (size_t)n * 2 * sizeof(float));
+  L.uvr = o;    o = al(o + (stereo ? (size_t)n * 2 * sizeof(float) : 0));
+  L.camr = o;   o = al(o + 16 * sizeof(float));
+  L.T = o;      o = al(o + 12 * sizeof(float));
+  L.mask = o;   o = al(o + (size_t)n);
+  L.maskr = o;  o = al(o + (stereo ? (size_t)n : 0));
+  L.gsw = o;    o = al(o + sizeof(int) * (size_t)ba::pose_only_sync_ints());
+  L.h2d_end = o;
+  L.meta = o;   o = al(o + 4 * sizeof(int));
+  L.iters = o;  o = al(o + (size_t)icap * sizeof(ba::PoIter));
+  L.dbg = o;    o = al(o + (size_t)icap * 12 * sizeof(float));
+  L.end = o;
+  return L;
+}
+
+int po_run(ba_handle *h, bool stereo, const float *X3, const float *uv2, const float *uvr2, int n,
+           float fx, float fy, float cx, float cy, const float *camr16, float *T12, uint8_t *mask,
+           uint8_t *mask_r, const ba_options *opt, ba_po_iter *iters, int cap, int *n_iter,
+           int *converged, float *debug_T12) {
+  if (use_device(h)) return -1;
+  static_assert(sizeof(ba::PoIter) == sizeof(ba_po_iter), "po iter layout");
+  const int max_it = opt->max_num_iterations;
+  const int icap = std::max(1, std::max(cap, max_it));
+  const PoLayout L = po_layout(n, icap, stereo);
+  if (L.end > h->po_cap) {  // grow the buffer pair (not in `allocs`: freed here and in free_device)
+    if (h->po_dev) (void)hipFree(h->po_dev);
+    if (h->po_host) (void)hipHostFree(h->po_host);
+    h->po_dev = h->po_host = nullptr;
+    h->po_cap = 0;
+    HIP_TRY(hipMalloc((void **)&h->po_dev, L.end));
+    HIP_TRY(hipHostMalloc((void **)&h->po_host, L.end, hipHostMallocDefault));
+    h->po_cap = L.end;
+  }
+  if (!h->po_part && h->dalloc(&h->po_part, (size_t)ba::pose_only_partial_floats())) return -1;
+  uint8_t *hb = h->po_host, *db = h->po_dev;
+  std::memcpy(hb + L.X, X3, (size_t)n * 3 * sizeof(float));
+  std::memcpy(hb + L.uv, uv2, (size_t)n * 2 * sizeof(float));
+  if (stereo) {
+    std::memcpy(hb + L.uvr, uvr2, (size_t)n * 2 * sizeof(float));
+    std::memcpy(hb + L.camr, camr16, 16 * sizeof(float));
+    std::memcpy(hb + L.maskr, mask_r, (size_t)n);
+  }
+  std::memcpy(hb + L.T, T12, 12 * sizeof(float));
+  std::memcpy(hb + L.mask, mask, (size_t)n);
+  std::memset(hb + L.gsw, 0, sizeof(int) * (size_t)ba::pose_only_sync_ints());
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(db, hb, L.h2d_end, hipMemcpyHostToDevice, s));
+  float *dT = (float *)(db + L.T), *ddbg = debug_T12 ? (float *)(db + L.dbg) : nullptr;
+  int rc;
+  if (stereo)
+    rc = ba::pose_only_stereo6_device(
+        (const float *)(db + L.X), (const float *)(db + L.uv), (const float *)(db + L.uvr), n, fx, fy,
+        cx, cy, (const float *)(db + L.camr), dT, db + L.mask, db + L.maskr, opt->threshold_huber_loss,
+        opt->threshold_step_size, opt->threshold_cost_change, opt->threshold_outlier_rejection, max_it,
+        (ba::PoIter *)(db + L.iters), icap, (int *)(db + L.meta), ddbg, (int *)(db + L.gsw), h->po_part, s);
+  else
+    rc = ba::pose_only_mono6_device(
+        (const float *)(db + L.X), (const float *)(db + L.uv), n, fx, fy, cx, cy, dT, db + L.mask,
+        opt->threshold_huber_loss, opt->threshold_step_size, opt->threshold_cost_change,
+        opt->threshold_outlier_rejection, max_it, (ba::PoIter *)(db + L.iters), icap,
+        (int *)(db + L.meta), ddbg, (int *)(db + L.gsw), h->po_part, s);
+  if (rc) return fail("pose-only kernel launch failed");
+  HIP_TRY(hipMemcpyAsync(hb + L.T, db + L.T, L.end - L.T, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int meta[4], gsw[2];
+  std::memcpy(meta, hb + L.meta, sizeof(meta));
+  std::memcpy(gsw, hb + L.gsw, sizeof(gsw));
+  if (gsw[1]) return fail("pose-only kernel: grid barrier timed out");
+  std::memcpy(T12, hb + L.T, 12 * sizeof(float));
+  std::memcpy(mask, hb + L.mask, (size_t)n);
+  if (stereo) std::memcpy(mask_r, hb + L.maskr, (size_t)n);
+  if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
+  const int rows = std::min(meta[2], cap);
+  if (iters && rows > 0) std::memcpy(iters, hb + L.iters, (size_t)rows * sizeof(ba_po_iter));
+  if (debug_T12 && meta[0] > 0)
+    std::memcpy(debug_T12, hb + L.dbg, (size_t)std::min(meta[0], cap) * 12 * sizeof(float));
+  if (n_iter) *n_iter = meta[0];
+  if (converged) *converged = meta[1];
+  return meta[3] ? 0 : 1;  // 1 = NaN pose, input left unchanged (reference :159-167)
+}
+}  // namespace
+
+extern "C" {
+
 int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
                        float fx, float fy, float cx, float cy, float *T12,
                        uint8_t *mask, const ba_options *opt, ba_po_iter *iters,
@@ -1101,53 +1201,8 @@ int ba_pose_only_mono6(ba_handle *h, const float *X3, const float *uv2, int n,
                        float *debug_T12) {
   if (!h || !X3 || !uv2 || n <= 0 || !T12 || !mask || !opt)
     return fail("ba_pose_only_mono6: bad argument");
-  if (use_device(h)) return -1;
-  static_assert(sizeof(ba::PoIter) == sizeof(ba_po_iter), "po iter layout");
-  const int max_it = opt->max_num_iterations;
-  const int icap = std::max(1, std::max(cap, max_it));
-  if (n > h->po_cap_n) {
-    if (h->dalloc(&h->po_X, (size_t)n * 3) || h->dalloc(&h->po_uv, (size_t)n * 2) ||
-        h->dalloc(&h->po_mask, (size_t)n))
-      return -1;
-    h->po_cap_n = n;
-  }
-  if (icap > h->po_cap_it || !h->po_T) {
-    if (h->dalloc(&h->po_iters, (size_t)icap) || h->dalloc(&h->po_dbg, (size_t)icap * 12))
-      return -1;
-    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4) ||
-                     h->dalloc(&h->po_gsync, (size_t)ba::pose_only_sync_ints()) ||
-                     h->dalloc(&h->po_part, (size_t)ba::pose_only_partial_floats())))
-      return -1;
-    h->po_cap_it = icap;
-  }
-  hipStream_t s = h->stream;
-  HIP_TRY(hipMemcpyAsync(h->po_X, X3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_uv, uv2, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_mask, mask, (size_t)n, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_T, T12, 12 * sizeof(float), hipMemcpyHostToDevice, s));
-  if (ba::pose_only_mono6_device(h->po_X, h->po_uv, n, fx, fy, cx, cy, h->po_T, h->po_mask,
-                                 opt->threshold_huber_loss, opt->threshold_step_size,
-                                 opt->threshold_cost_change, opt->threshold_outlier_rejection,
-                                 max_it, h->po_iters, icap, h->po_meta,
-                                 debug_T12 ? h->po_dbg : nullptr, h->po_gsync, h->po_part, s))
-    return fail("pose-only kernel launch failed");
-  int meta[4] = {0, 0, 0, 0}, gsw[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(meta, h->po_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(gsw, h->po_gsync, sizeof(gsw), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(T12, h->po_T, 12 * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(mask, h->po_mask, (size_t)n, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (gsw[1]) return fail("pose-only kernel: grid barrier timed out");
-  if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
-  const int rows = std::min(meta[2], cap);
-  if (iters && rows > 0)
-    HIP_TRY(hipMemcpy(iters, h->po_iters, (size_t)rows * sizeof(ba_po_iter), hipMemcpyDeviceToHost));
-  if (debug_T12 && meta[0] > 0)
-    HIP_TRY(hipMemcpy(debug_T12, h->po_dbg, (size_t)std::min(meta[0], cap) * 12 * sizeof(float),
-                      hipMemcpyDeviceToHost));
-  if (n_iter) *n_iter = meta[0];
-  if (converged) *converged = meta[1];
-  return meta[3] ? 0 : 1;  // 1 = NaN pose, input left unchanged (reference :159-167)
+  return po_run(h, false, X3, uv2, nullptr, n, fx, fy, cx, cy, nullptr, T12, mask, nullptr, opt,
+                iters, cap, n_iter, converged, debug_T12);
 }
 
 int ba_pose_only_stereo6(ba_handle *h, const float *X3, const float *uv2,
@@ -1159,7 +1214,6 @@ int ba_pose_only_stereo6(ba_handle *h, const float *X3, const float *uv2,
   if (!h || !X3 || !uv2 || !uvr2 || n <= 0 || !intr_l4 || !intr_r4 || !T_lr12 || !T12 ||
       !mask || !mask_r || !opt)
     return fail("ba_pose_only_stereo6: bad argument");
-  const float fx = intr_l4[0], fy = intr_l4[1], cx = intr_l4[2], cy = intr_l4[3];
   // right camera record: fx fy cx cy, then pose_right_to_left = left_to_right^-1
   // (reference :226) as R (9, row-major) and t (3)
   float camr[16];
@@ -1169,64 +1223,8 @@ int ba_pose_only_stereo6(ba_handle *h, const float *X3, const float *uv2,
   for (int r = 0; r < 3; ++r)
     camr[13 + r] = -(camr[4 + r * 3 + 0] * T_lr12[9] + camr[4 + r * 3 + 1] * T_lr12[10] +
                      camr[4 + r * 3 + 2] * T_lr12[11]);
-  if (use_device(h)) return -1;
-  static_assert(sizeof(ba::PoIter) == sizeof(ba_po_iter), "po iter layout");
-  const int max_it = opt->max_num_iterations;
-  const int icap = std::max(1, std::max(cap, max_it));
-  if (n > h->po_cap_n) {
-    if (h->dalloc(&h->po_X, (size_t)n * 3) || h->dalloc(&h->po_uv, (size_t)n * 2) ||
-        h->dalloc(&h->po_mask, (size_t)n))
-      return -1;
-    h->po_cap_n = n;
-  }
-  if (n > h->po_cap_nr || !h->po_camr) {
-    if (h->dalloc(&h->po_uvr, (size_t)n * 2) || h->dalloc(&h->po_maskr, (size_t)n) ||
-        (!h->po_camr && h->dalloc(&h->po_camr, (size_t)16)))
-      return -1;
-    h->po_cap_nr = n;
-  }
-  if (icap > h->po_cap_it || !h->po_T) {
-    if (h->dalloc(&h->po_iters, (size_t)icap) || h->dalloc(&h->po_dbg, (size_t)icap * 12))
-      return -1;
-    if (!h->po_T && (h->dalloc(&h->po_T, (size_t)12) || h->dalloc(&h->po_meta, (size_t)4) ||
-                     h->dalloc(&h->po_gsync, (size_t)ba::pose_only_sync_ints()) ||
-                     h->dalloc(&h->po_part, (size_t)ba::pose_only_partial_floats())))
-      return -1;
-    h->po_cap_it = icap;
-  }
-  hipStream_t s = h->stream;
-  HIP_TRY(hipMemcpyAsync(h->po_X, X3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_uv, uv2, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_mask, mask, (size_t)n, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_T, T12, 12 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_uvr, uvr2, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_maskr, mask_r, (size_t)n, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->po_camr, camr, sizeof(camr), hipMemcpyHostToDevice, s));
-  if (ba::pose_only_stereo6_device(h->po_X, h->po_uv, h->po_uvr, n, fx, fy, cx, cy, h->po_camr,
-                                   h->po_T, h->po_mask, h->po_maskr,
-                                 opt->threshold_huber_loss, opt->threshold_step_size,
-                                 opt->threshold_cost_change, opt->threshold_outlier_rejection,
-                                 max_it, h->po_iters, icap, h->po_meta,
-                                 debug_T12 ? h->po_dbg : nullptr, h->po_gsync, h->po_part, s))
-    return fail("pose-only kernel launch failed");
-  int meta[4] = {0, 0, 0, 0}, gsw[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(meta, h->po_meta, sizeof(meta), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(gsw, h->po_gsync, sizeof(gsw), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(T12, h->po_T, 12 * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(mask, h->po_mask, (size_t)n, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(mask_r, h->po_maskr, (size_t)n, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (gsw[1]) return fail("pose-only kernel: grid barrier timed out");
-  if (max_it <= 0) { meta[0] = 0; meta[1] = 1; meta[2] = 0; meta[3] = 1; }
-  const int rows = std::min(meta[2], cap);
-  if (iters && rows > 0)
-    HIP_TRY(hipMemcpy(iters, h->po_iters, (size_t)rows * sizeof(ba_po_iter), hipMemcpyDeviceToHost));
-  if (debug_T12 && meta[0] > 0)
-    HIP_TRY(hipMemcpy(debug_T12, h->po_dbg, (size_t)std::min(meta[0], cap) * 12 * sizeof(float),
-                      hipMemcpyDeviceToHost));
-  if (n_iter) *n_iter = meta[0];
-  if (converged) *converged = meta[1];
-  return meta[3] ? 0 : 1;  // 1 = NaN pose, input left unchanged (reference :159-167)
+  return po_run(h, true, X3, uv2, uvr2, n, intr_l4[0], intr_l4[1], intr_l4[2], intr_l4[3], camr, T12,
+                mask, mask_r, opt, iters, cap, n_iter, converged, debug_T12);
 }
 
 }  // extern "C"

@@ -435,7 +435,7 @@ int pose_only_mono6_device(const float *dX3, const float *duv2, int n, float fx,
                            float thr_cost, float thr_out, int max_it,
                            PoIter *d_iters, int cap, int *d_meta,
                            float *d_debug, int *d_gsync, float *d_partial, hipStream_t s) {
-  if (hipMemsetAsync(d_gsync, 0, 2 * sizeof(int), s) != hipSuccess) return -1;
+  // d_gsync must be zero on entry (the caller's single H2D copy covers it)
   hipLaunchKernelGGL(k_pose_only6<false>, dim3(po_groups(n)), dim3(kPoThreads), 0, s, dX3, duv2,
                      (const float *)nullptr, n, fx, fy, cx, cy, (const float *)nullptr, dT12,
                      dmask, (uint8_t *)nullptr, thr_huber, thr_step, thr_cost, thr_out, max_it,
@@ -449,7 +449,7 @@ int pose_only_stereo6_device(const float *dX3, const float *duvl2, const float *
                              float thr_step, float thr_cost, float thr_out, int max_it,
                              PoIter *d_iters, int cap, int *d_meta, float *d_debug,
                              int *d_gsync, float *d_partial, hipStream_t s) {
-  if (hipMemsetAsync(d_gsync, 0, 2 * sizeof(int), s) != hipSuccess) return -1;
+  // d_gsync must be zero on entry (the caller's single H2D copy covers it)
   hipLaunchKernelGGL(k_pose_only6<true>, dim3(po_groups(n)), dim3(kPoThreads), 0, s, dX3, duvl2,
                      duvr2, n, fx, fy, cx, cy, d_cam_r16, dT12, dmask_l, dmask_r, thr_huber,
                      thr_step, thr_cost, thr_out, max_it, d_iters, cap, d_meta, d_debug, d_gsync,
