@@ -241,11 +241,11 @@ def main():
             kbytes = {
                 "k_cost": 24 * n_obs + 24 * M_glob + 96 * n_pose,
                 "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 96 * P +
-                144 * M_glob,
+                120 * M_glob,
                 "k_lin_poses": 24 * O_opt + 24 * M_glob,
                 "k_schur_lds": 96 * P + 72 * M_glob + 4 * T,
                 "k_schur_final": 288 * B,
-                "k_backsub_update": 96 * P + 216 * M_glob,
+                "k_backsub_update": 96 * P + 192 * M_glob,
             }
             tot = {k: v[0] / n_prof for k, v in km.items() if v[1]}
             dense = sum(tot.get(k, 0.0) for k in

@@ -486,7 +486,7 @@ int ba_finalize(ba_handle *h) {
 
   // per-iteration storage
   if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.b, (size_t)pl.M * 3) ||
-      h->dalloc(&d.Cinv, (size_t)pl.M * 6) || h->dalloc(&d.Cinvb, (size_t)pl.M * 3) ||
+      h->dalloc(&d.Cinv, (size_t)pl.M * 6) ||
       h->dalloc(&d.W, (size_t)pl.P * ba::kWStride) ||
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) || h->dalloc(&d.A, (size_t)pl.N * 36) ||
       h->dalloc(&d.a, (size_t)pl.N * 6) ||
@@ -909,7 +909,23 @@ int ba_get_C(ba_handle *h, double *C9, double *b3) {
 int ba_get_Cinv(ba_handle *h, double *Cinv9, double *Cinvb3) {
   if (!h || !h->finalized) return fail("ba_get_Cinv: not finalized");
   if (use_device(h)) return -1;
-  return get_sym_vec(h, h->d.Cinv, h->d.Cinvb, Cinv9, Cinvb3);
+  // Cinv_i b_i is not stored on the device (k_backsub_update forms it): same expression here
+  const ba::Plan &pl = h->plan;
+  std::vector<double> s6, b3;
+  if (download(s6, h->d.Cinv, (size_t)pl.M * 6, h->stream)) return -1;
+  if (download(b3, h->d.b, (size_t)pl.M * 3, h->stream)) return -1;
+  for (int i = 0; i < pl.M; ++i) {
+    const int g = pl.iopt_of_user[pl.pt_user_of_int[i]];
+    const double *ci = &s6[(size_t)i * 6], *b = &b3[(size_t)i * 3];
+    if (Cinv9) expand_sym3(ci, Cinv9 + (size_t)g * 9);
+    if (Cinvb3) {
+      double *o = Cinvb3 + (size_t)g * 3;
+      o[0] = ci[0] * b[0] + ci[1] * b[1] + ci[2] * b[2];
+      o[1] = ci[1] * b[0] + ci[3] * b[1] + ci[4] * b[2];
+      o[2] = ci[2] * b[0] + ci[4] * b[1] + ci[5] * b[2];
+    }
+  }
+  return 0;
 }
 
 int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18) {

@@ -99,7 +99,6 @@ struct DevProblem {
   double *Cd;      // M*6   damped C_i upper (00 01 02 11 12 22)
   double *b;       // M*3
   double *Cinv;    // M*6   symmetric inverse upper
-  double *Cinvb;   // M*3
   double *W;       // P*kWStride  compact B_ji (see kWStride)
   double *Apart;   // n_achunk*27
   double *A;       // N*36  damped, full

@@ -610,10 +610,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
   double *Io = d.Cinv + (size_t)i * 6;
 #pragma unroll
   for (int k = 0; k < 6; ++k) Io[k] = ci[k];
-  double *cbo = d.Cinvb + (size_t)i * 3;
-  cbo[0] = ci[0] * b0 + ci[1] * b1 + ci[2] * b2;
-  cbo[1] = ci[1] * b0 + ci[3] * b1 + ci[4] * b2;
-  cbo[2] = ci[2] * b0 + ci[4] * b1 + ci[5] * b2;
+  // (Cinv_i b_i is formed where it is used, in k_backsub_update: 24 bytes per
+  //  landmark less to write here and to read there)
 }
 
 // --------------------------------------------------------------------------
@@ -1260,18 +1258,16 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
     const int i = l0 + tid;
     const bool own = tid < nl;
     int64_t q0 = 0, q1 = 0;
-    double ci[6], cb[3], Xi[3], bi[3], C[6];
+    double ci[6], Xi[3], bi[3], C[6];
 #pragma unroll
     for (int e = 0; e < 6; ++e) ci[e] = C[e] = 0.0;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) cb[e] = Xi[e] = bi[e] = 0.0;
+    for (int e = 0; e < 3; ++e) Xi[e] = bi[e] = 0.0;
     if (own) {
       q0 = d.lm_pair_ptr[i];
       q1 = d.lm_pair_ptr[i + 1];
 #pragma unroll
       for (int e = 0; e < 6; ++e) ci[e] = d.Cinv[(size_t)i * 6 + e];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) cb[e] = d.Cinvb[(size_t)i * 3 + e];
 #pragma unroll
       for (int e = 0; e < 3; ++e) Xi[e] = Xc[(size_t)i * 3 + e];
 #pragma unroll
@@ -1350,9 +1346,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
     }
     double est = 0.0, nrm = 0.0;
     if (own) {
-      const double y0 = cb[0] - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);
-      const double y1 = cb[1] - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);
-      const double y2 = cb[2] - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);
+      // Cinv_i b_i (reference :855), formed here instead of being stored
+      const double cb0 = ci[0] * bi[0] + ci[1] * bi[1] + ci[2] * bi[2];
+      const double cb1 = ci[1] * bi[0] + ci[3] * bi[1] + ci[4] * bi[2];
+      const double cb2 = ci[2] * bi[0] + ci[4] * bi[1] + ci[5] * bi[2];
+      const double y0 = cb0 - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);
+      const double y1 = cb1 - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);
+      const double y2 = cb2 - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);
       double *yo = d.y + (size_t)i * 3;
       yo[0] = y0; yo[1] = y1; yo[2] = y2;
       double *Xo = Xt + (size_t)i * 3;
