@@ -46,7 +46,7 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
-PMC_SUMMARY = {"C4": "profiles/r01_c4_pmc_fetch_write_v16.txt"}
+PMC_SUMMARY = {"C4": "profiles/r01_c4_pmc_fetch_write_v17.txt"}
 
 
 def pmc_traffic(kernel, config):
