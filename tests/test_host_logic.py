@@ -151,3 +151,22 @@ def test_facade_bulk_api_bookkeeping():
     s.AddObservations(0, np.array([0, 1, 9]), np.array([0, 20, 1]),
                       np.zeros((3, 2)))
     assert s.num_total_observations_ == 1        # two invalid rows dropped
+
+
+def test_documents_cite_existing_profile_files():
+    """DESIGN.md / README.md / bench.py name files under profiles/: every one of
+    them must be committed (the per-round sets replace each other)."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cited = set()
+    for name in ("DESIGN.md", "README.md", "bench.py", "profiles/README.md"):
+        text = open(os.path.join(root, name)).read()
+        cited |= set(re.findall(r"profiles/(r01_[A-Za-z0-9_{},.]+?\.(?:json|csv|txt))", text))
+    assert cited
+    for c in sorted(cited):
+        m = re.search(r"\{([^}]*)\}", c)
+        names = [c[:m.start()] + v + c[m.end():] for v in m.group(1).split(",")] if m else [c]
+        for n in names:
+            assert glob.glob(os.path.join(root, "profiles", n)), "missing profiles/" + n
