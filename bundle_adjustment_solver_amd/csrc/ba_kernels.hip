@@ -1081,6 +1081,16 @@ __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t bl
                                                  double (*part)[42]) {
   const int q = threadIdx.x / 42, e = threadIdx.x - q * 42;
   const int j = d.sblk_j[blk], k = d.sblk_k[blk];
+  // what the 42 finishing threads need besides the sums depends on (j, k) only:
+  // requested now, one load level earlier than after the barrier
+  double pre = 0.0;
+  int pcj = 0, pck = 0;
+  if (threadIdx.x < 42 && (e < 36 || j == k)) {
+    if (e >= 36) pre = d.a[(size_t)j * 6 + (e - 36)];
+    else if (j == k) pre = d.A[(size_t)j * 36 + e];
+    pcj = d.pose_col[j];
+    pck = d.pose_col[k];
+  }
   if (q < 6 && (e < 36 || j == k)) {
     double s = 0.0;
     const int64_t c1 = d.blk_contrib_ptr[blk + 1];
@@ -1098,17 +1108,17 @@ __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t bl
   for (int p = 1; p < 6; ++p) s += part[p][e];
   if (e >= 36) {  // rhs of pose j
     const int r = e - 36;
-    const double val = d.a[(size_t)j * 6 + r] - s;
+    const double val = pre - s;
     d.Spk[(size_t)d.B * 36 + (size_t)j * 6 + r] = val;
     if (DIRECT)  // rhs rides as row `npad` of the dense matrix (see k_scatter)
-      d.L[(size_t)(d.pose_col[j] + r) * d.ld + d.npad] = val;
+      d.L[(size_t)(pcj + r) * d.ld + d.npad] = val;
     return;
   }
-  const double val = (j == k) ? (d.A[(size_t)j * 36 + e] - s) : -s;
+  const double val = (j == k) ? (pre - s) : -s;
   d.Spk[(size_t)blk * 36 + e] = val;
   if (DIRECT) {  // same placement as k_scatter
     const int r = e / 6, c = e % 6;
-    int row = d.pose_col[k] + c, col = d.pose_col[j] + r;
+    int row = pck + c, col = pcj + r;
     if (j == k && row < col) return;
     if (row < col) {
       const int t2 = row;
