@@ -114,7 +114,7 @@ def main():
     import __graft_entry__ as ge
     ge.build(only_if_missing=True)
     from bundle_adjustment_solver_amd import scenes
-    from bundle_adjustment_solver_amd._lib import BaOptions
+    from bundle_adjustment_solver_amd._lib import make_options
     from bundle_adjustment_solver_amd.solver import BaProblem
     from oracle import oracle_py as O
 
@@ -145,8 +145,8 @@ def main():
     N = p.N
     M_glob = int((pr["pt_fixed"] == 0).sum())
     # the LM loop must not stop inside the timed region: thresholds < 0
-    opt = O.make_options(max_iter=args.warmup + args.steps + 1, thr_step=-1.0,
-                         thr_cost=-1.0, cls=BaOptions)
+    opt = make_options(max_iter=args.warmup + args.steps + 1, thr_step=-1.0,
+                         thr_cost=-1.0)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -209,8 +209,7 @@ def main():
         p.get_stage_ms(reset=True)
         p.get_kernel_ms(reset=True)
         n_prof = min(5, max(1, args.steps))
-        opt2 = O.make_options(max_iter=n_prof, thr_step=-1.0, thr_cost=-1.0,
-                              cls=BaOptions)
+        opt2 = make_options(max_iter=n_prof, thr_step=-1.0, thr_cost=-1.0)
         p.lm_begin(opt2)
         p.lm_iterate(n_prof)
         p.lm_sync()

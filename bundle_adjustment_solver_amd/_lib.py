@@ -25,6 +25,24 @@ class BaOptions(C.Structure):
     ]
 
 
+def make_options(max_iter=50, thr_step=1e-5, thr_cost=1e-5, huber=1.0,
+                 outlier=2.0, lambda0=100.0, dec=0.33, inc=3.0,
+                 gauss_newton=False):
+    """ba_options with the defaults of reference test/test_ba.cpp:279-290
+    (lambda0 100, ratios 0.33 / 3.0, Huber 1.0)."""
+    o = BaOptions()
+    o.gauss_newton = 1 if gauss_newton else 0
+    o.threshold_step_size = thr_step
+    o.threshold_cost_change = thr_cost
+    o.threshold_huber_loss = huber
+    o.threshold_outlier_rejection = outlier
+    o.max_num_iterations = max_iter
+    o.initial_lambda = lambda0
+    o.decrease_ratio_lambda = dec
+    o.increase_ratio_lambda = inc
+    return o
+
+
 class BaIterInfo(C.Structure):
     """ba_iter_info — OptimizationInfo (reference
     core/solver_option_and_summary.h:37-46) + trust-region internals."""

@@ -183,6 +183,91 @@ void ldlt3_inverse(const double C[9], double Cinv[9]) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// FAST-SOLVE MODE (test infrastructure only, NOT a restatement of the
+// reference): envelope ("skyline") LDL^T WITHOUT pivoting of the same reduced
+// system S x = rhs that reference :905 hands to Eigen's pivoted LDLT.  S is
+// block sparse (two poses couple only through common landmarks), so row r of
+// the factor has no entries left of first[r] = the first structurally
+// non-zero column of row r of S; the work drops from n^3/3 to sum_r w_r^2
+// (C4: 71 GFLOP -> ~10 MFLOP) and the BASELINE-size trajectories can be
+// followed for many iterations.  S is symmetric positive definite whenever the
+// pivoted factorisation meets no zero pivot, and then both give the same x up
+// to roundoff (tests/test_oracle_pins.py cross-checks them to 1e-9 on C1 and
+// C2).  A zero pivot (pose without observations: zero row and column) yields
+// x = 0 for that unknown, as the pseudo-inverted D of Eigen's solve does.
+// ---------------------------------------------------------------------------
+struct Skyline {
+  int n = 0;
+  std::vector<int> first;        // first stored column of row r (<= r)
+  std::vector<size_t> rowp;      // offset of S(r, first[r]) in `v`
+  std::vector<double> v;         // rows of the envelope, diagonal included
+  std::vector<double> t;
+
+  // a: n x n row-major, lower triangle read
+  void compute(int n_, const double *a) {
+    n = n_;
+    first.resize(n);
+    rowp.resize(n + 1);
+    size_t tot = 0;
+    for (int r = 0; r < n; ++r) {
+      const double *row = a + (size_t)r * n;
+      int f = r;
+      for (int c = 0; c < r; ++c)
+        if (row[c] != 0.0) {
+          f = c;
+          break;
+        }
+      first[r] = f;
+      rowp[r] = tot;
+      tot += (size_t)(r - f + 1);
+    }
+    rowp[n] = tot;
+    v.resize(tot);
+    t.resize(n);
+    for (int r = 0; r < n; ++r)
+      std::memcpy(&v[rowp[r]], a + (size_t)r * n + first[r],
+                  sizeof(double) * (size_t)(r - first[r] + 1));
+    // row by row: t_c = L(r,c) D_c, then L(r,c) = t_c / D_c, D_r
+    for (int r = 0; r < n; ++r) {
+      double *Lr = &v[rowp[r]] - first[r];  // Lr[c], first[r] <= c <= r
+      for (int c = first[r]; c < r; ++c) {
+        const double *Lc = &v[rowp[c]] - first[c];
+        const int k0 = std::max(first[r], first[c]);
+        double s = Lr[c];
+        for (int k = k0; k < c; ++k) s -= t[k] * Lc[k];
+        t[c] = s;
+      }
+      double d = Lr[r];
+      for (int c = first[r]; c < r; ++c) {
+        const double dc = v[rowp[c] + (size_t)(c - first[c])];
+        const double l = (std::fabs(dc) > 0.0) ? t[c] / dc : t[c];
+        Lr[c] = l;
+        d -= t[c] * l;
+      }
+      Lr[r] = d;
+    }
+  }
+
+  void solve(double *b) const {
+    for (int r = 0; r < n; ++r) {  // L z = b
+      const double *Lr = &v[rowp[r]] - first[r];
+      double s = b[r];
+      for (int c = first[r]; c < r; ++c) s -= Lr[c] * b[c];
+      b[r] = s;
+    }
+    for (int r = 0; r < n; ++r) {  // D pseudo-inverse
+      const double d = v[rowp[r] + (size_t)(r - first[r])];
+      b[r] = (std::fabs(d) > DBL_MIN) ? b[r] / d : 0.0;
+    }
+    for (int r = n - 1; r >= 0; --r) {  // L^T x = w
+      const double *Lr = &v[rowp[r]] - first[r];
+      const double xr = b[r];
+      for (int c = first[r]; c < r; ++c) b[c] -= Lr[c] * xr;
+    }
+  }
+};
+
 // se3 exponential, reference core/full_bundle_adjustment_solver.cpp:1046-1082
 template <typename T>
 void se3_exp(const T xi[6], T R[9], T t[3]) {
@@ -274,6 +359,7 @@ struct ba_oracle {
   std::vector<double> X_bak;
 
   bool dense_faithful = false;
+  bool fast_solve = false;          // Skyline instead of the pivoted LDLT
   std::vector<double> dense_grid;   // 4 * N*M*18 doubles when dense_faithful
 
   double stage_ms[4] = {0, 0, 0, 0};
@@ -404,6 +490,8 @@ void ba_oracle_set_dense_faithful(ba_oracle *o, int on) {
   else
     std::vector<double>().swap(o->dense_grid);
 }
+
+void ba_oracle_set_fast_solve(ba_oracle *o, int on) { o->fast_solve = on != 0; }
 
 int ba_oracle_num_opt_poses(const ba_oracle *o) { return o->N; }
 int ba_oracle_num_opt_points(const ba_oracle *o) { return o->M; }
@@ -599,9 +687,15 @@ void ba_oracle_schur(ba_oracle *o) {
 // reference :905  x = S.ldlt().solve(rhs)
 void ba_oracle_solve_reduced(ba_oracle *o) {
   const int n6 = 6 * o->N;
+  o->x = o->rhs;
+  if (o->fast_solve) {  // test-only shortcut, see Skyline above
+    Skyline f;
+    f.compute(n6, o->S.data());
+    f.solve(o->x.data());
+    return;
+  }
   Ldlt f;
   f.compute(n6, o->S.data());
-  o->x = o->rhs;
   f.solve(o->x.data());
 }
 

@@ -78,6 +78,14 @@ void ba_oracle_destroy(ba_oracle *o);
  * dense N x M block grids every iteration (timing fidelity only). */
 void ba_oracle_set_dense_faithful(ba_oracle *o, int on);
 
+/* fast_solve != 0: the reduced system is solved by an envelope LDL^T without
+ * pivoting instead of the restated Eigen pivoted LDLT (same x up to roundoff
+ * for positive definite S; cross-checked in tests/test_oracle_pins.py).  A
+ * TEST shortcut for long trajectories at the BASELINE sizes, where the
+ * reference-style dense factorisation takes 17 s per iteration; not a
+ * restatement of reference arithmetic. */
+void ba_oracle_set_fast_solve(ba_oracle *o, int on);
+
 int ba_oracle_num_opt_poses(const ba_oracle *o);
 int ba_oracle_num_opt_points(const ba_oracle *o);
 int64_t ba_oracle_num_pairs(const ba_oracle *o);

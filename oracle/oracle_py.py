@@ -59,6 +59,7 @@ def load():
                                    _D, _U, C.c_int64, _I, _I, _I, _D]
     L.ba_oracle_destroy.argtypes = [C.c_void_p]
     L.ba_oracle_set_dense_faithful.argtypes = [C.c_void_p, C.c_int]
+    L.ba_oracle_set_fast_solve.argtypes = [C.c_void_p, C.c_int]
     for n in ("ba_oracle_num_opt_poses", "ba_oracle_num_opt_points"):
         getattr(L, n).restype = C.c_int
         getattr(L, n).argtypes = [C.c_void_p]
@@ -107,9 +108,11 @@ def _dp(a):
 
 
 def make_options(max_iter=50, thr_step=1e-5, thr_cost=1e-5, huber=1.0,
-                 outlier=2.0, lambda0=100.0, dec=0.33, inc=3.0, cls=None,
+                 outlier=2.0, lambda0=100.0, dec=0.33, inc=3.0,
                  gauss_newton=False):
-    o = (cls or OracleOptions)()
+    """Options of the ORACLE (the product builds its own ba_options with
+    bundle_adjustment_solver_amd._lib.make_options)."""
+    o = OracleOptions()
     o.gauss_newton = 1 if gauss_newton else 0
     o.threshold_step_size = thr_step
     o.threshold_cost_change = thr_cost
@@ -157,6 +160,11 @@ class Oracle:
 
     def set_dense_faithful(self, on):
         self.L.ba_oracle_set_dense_faithful(self.o, int(on))
+
+    def set_fast_solve(self, on):
+        """Envelope LDL^T without pivoting for the reduced system (test
+        shortcut at the BASELINE sizes; see ba_oracle.h)."""
+        self.L.ba_oracle_set_fast_solve(self.o, int(on))
 
     def cost(self):
         return self.L.ba_oracle_cost(self.o)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from bundle_adjustment_solver_amd import scenes
-from bundle_adjustment_solver_amd._lib import BaOptions
+from bundle_adjustment_solver_amd._lib import make_options
 from bundle_adjustment_solver_amd.solver import BaProblem
 from oracle import oracle_py as O
 
@@ -164,8 +164,8 @@ def test_lm_trajectory(kind, built):
     n_it = 25
     g = make_gpu(pr)
     o = O.Oracle(pr)
-    rows, conv = g.solve(O.make_options(max_iter=n_it, thr_step=1e-7,
-                                        thr_cost=1e-7, cls=BaOptions))
+    rows, conv = g.solve(make_options(max_iter=n_it, thr_step=1e-7,
+                                        thr_cost=1e-7))
     orows, oconv = o.solve(O.make_options(max_iter=n_it, thr_step=1e-7,
                                           thr_cost=1e-7))
     assert len(rows) == len(orows) and conv == oconv
@@ -190,8 +190,8 @@ def test_converges_to_truth(built):
     sc = scenes.synthetic_ba_scene(20, 800, 5, True, seed=3)
     pr = scenes.scaled_problem(sc)
     g = make_gpu(pr)
-    rows, conv = g.solve(O.make_options(max_iter=60, thr_step=1e-9,
-                                        thr_cost=1e-9, cls=BaOptions))
+    rows, conv = g.solve(make_options(max_iter=60, thr_step=1e-9,
+                                        thr_cost=1e-9))
     X = g.get_points()[0] / 0.01
     err = np.linalg.norm(X - sc["X_true"], axis=1)
     err0 = np.linalg.norm(sc["X_init"] - sc["X_true"], axis=1)
@@ -229,8 +229,7 @@ def test_edge_cases(built):
     assert relerr(x, ox) < 1e-6 and relerr(y, oy) < 1e-6
     jlast = o.N - 1                      # pose 11 -> zero row/col -> x = 0
     assert (x[jlast] == 0).all() and np.abs(ox[jlast]).max() == 0
-    rows, _ = g.solve(O.make_options(max_iter=10, thr_step=0, thr_cost=0,
-                                     cls=BaOptions))
+    rows, _ = g.solve(make_options(max_iter=10, thr_step=0, thr_cost=0))
     orows, _ = o.solve(O.make_options(max_iter=10, thr_step=0, thr_cost=0))
     for a, b in zip(rows, orows):
         assert a.iteration_status == b.iteration_status
@@ -282,8 +281,8 @@ def test_reproducible_bits(built):
         outs = []
         for _ in range(3):
             g = make_gpu(pr)
-            rows, _ = g.solve(O.make_options(max_iter=14, thr_step=0,
-                                             thr_cost=0, cls=BaOptions))
+            rows, _ = g.solve(make_options(max_iter=14, thr_step=0,
+                                             thr_cost=0))
             outs.append((g.get_poses().copy(), g.get_points()[0].copy(),
                          [r.trial_cost for r in rows]))
         for o in outs[1:]:
@@ -372,8 +371,7 @@ def _compare_solve(pr, iters=6, tol_cost=1e-7, tol_par=1e-6):
     S, rhs = g.get_S()
     oS, orhs = o.get_S()
     assert relerr(S, oS) < 1e-9 and relerr(rhs, orhs) < 1e-9
-    rows, _ = g.solve(O.make_options(max_iter=iters, thr_step=0, thr_cost=0,
-                                     cls=BaOptions))
+    rows, _ = g.solve(make_options(max_iter=iters, thr_step=0, thr_cost=0))
     orows, _ = o.solve(O.make_options(max_iter=iters, thr_step=0, thr_cost=0))
     assert len(rows) == len(orows) == iters
     for a, b in zip(rows, orows):
@@ -433,7 +431,7 @@ def test_all_points_fixed_and_single_free_pose(built):
     sc["pt_fixed"][:] = True
     pr = scenes.scaled_problem(sc)
     g, o = make_gpu(pr), O.Oracle(pr)
-    rows, _ = g.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0, cls=BaOptions))
+    rows, _ = g.solve(make_options(max_iter=5, thr_step=0, thr_cost=0))
     orows, _ = o.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0))
     for a, b in zip(rows, orows):
         assert a.iteration_status == b.iteration_status
@@ -451,7 +449,7 @@ def test_all_poses_fixed_and_no_observations(built):
     sc["pose_fixed"][:] = True
     pr = scenes.scaled_problem(sc)
     g, o = make_gpu(pr), O.Oracle(pr)
-    rows, _ = g.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0, cls=BaOptions))
+    rows, _ = g.solve(make_options(max_iter=5, thr_step=0, thr_cost=0))
     orows, _ = o.solve(O.make_options(max_iter=5, thr_step=0, thr_cost=0))
     assert len(rows) == len(orows)
     for a, b in zip(rows, orows):
@@ -464,7 +462,7 @@ def test_all_poses_fixed_and_no_observations(built):
         sc[k] = sc[k][:0]
     pr = scenes.scaled_problem(sc)
     g, o = make_gpu(pr), O.Oracle(pr)
-    rows, _ = g.solve(O.make_options(max_iter=3, thr_step=0, thr_cost=0, cls=BaOptions))
+    rows, _ = g.solve(make_options(max_iter=3, thr_step=0, thr_cost=0))
     orows, _ = o.solve(O.make_options(max_iter=3, thr_step=0, thr_cost=0))
     assert [r.iteration_status for r in rows] == [r.iteration_status for r in orows]
     assert np.array_equal(g.get_points()[0], pr["pt_X"])
@@ -511,7 +509,7 @@ def test_gauss_newton_mode_of_the_refactored_solver(built):
     pr = scenes.scaled_problem(sc)
     g, o = make_gpu(pr), O.Oracle(pr)
     kw = dict(max_iter=6, thr_step=0, thr_cost=0, lambda0=1e-3, gauss_newton=True)
-    rows, _ = g.solve(O.make_options(cls=BaOptions, **kw))
+    rows, _ = g.solve(make_options(**kw))
     orows, _ = o.solve(O.make_options(**kw))
     assert len(rows) == len(orows) == 6
     for a, b in zip(rows, orows):
@@ -555,12 +553,12 @@ def test_full_size_configs_properties(built):
     its noise-free scene; C4 is bitwise reproducible run to run, accepted steps
     never increase the cost, and one handle re-solved from the same start
     repeats its trajectory."""
-    opts = dict(thr_step=0, thr_cost=0, cls=BaOptions)
+    opts = dict(thr_step=0, thr_cost=0)
     # ---- C2: 200 poses / 50 k landmarks / 500 k observations (mono) ----
     sc = scenes.config_scene("C2")
     pr = scenes.scaled_problem(sc)
     g = make_gpu(pr)
-    rows, _ = g.solve(O.make_options(max_iter=40, **opts))
+    rows, _ = g.solve(make_options(max_iter=40, **opts))
     X0 = pr["pt_X"]
     Xt = sc["X_true"] * 0.01
     e0 = np.linalg.norm(X0 - Xt, axis=1)
@@ -577,7 +575,7 @@ def test_full_size_configs_properties(built):
     logs = []
     for _ in range(2):
         g = make_gpu(pr)
-        rows, _ = g.solve(O.make_options(max_iter=6, **opts))
+        rows, _ = g.solve(make_options(max_iter=6, **opts))
         logs.append([(r.cost, r.damping_term, r.iteration_status, r.trial_cost)
                      for r in rows])
         P, X = g.get_poses().copy(), g.get_points()[0].copy()
@@ -601,7 +599,7 @@ def test_handles_release_their_device_memory(built):
 
     sc = scenes.synthetic_ba_scene(30, 4000, 5, True, seed=3)
     pr = scenes.scaled_problem(sc)
-    opt = O.make_options(max_iter=4, thr_step=0, thr_cost=0, cls=BaOptions)
+    opt = make_options(max_iter=4, thr_step=0, thr_cost=0)
     def cycle():
         g = make_gpu(pr)
         g.solve(opt)
@@ -623,38 +621,85 @@ def test_handles_release_their_device_memory(built):
     assert before - after < 16 << 20, (before, after)
 
 
-def test_config_c2_and_c3_first_iterations_match_oracle(built):
-    """BASELINE.json configs C2 (mono 200 / 50 k / 500 k) and C3 (stereo 500 /
-    200 k / 2 M) directly against the oracle: two LM iterations each (the
-    oracle's dense LDLT makes a C3 iteration take a few seconds)."""
-    for name in ("C2", "C3"):
-        sc = scenes.config_scene(name)
-        pr = scenes.scaled_problem(sc)
-        g, o = make_gpu(pr), O.Oracle(pr)
-        rows, _ = g.solve(O.make_options(max_iter=2, thr_step=0, thr_cost=0, cls=BaOptions))
-        orows, _ = o.solve(O.make_options(max_iter=2, thr_step=0, thr_cost=0))
-        assert len(rows) == len(orows) == 2
-        for a, b in zip(rows, orows):
-            assert a.iteration_status == b.iteration_status
-            assert relerr(a.trial_cost, b.trial_cost) < 1e-8
-            assert relerr(a.damping_term, b.damping_term) < 1e-12
-        # north-star tolerance: 1e-4 relative on poses / points
-        assert relerr(g.get_poses(), o.get_poses()) < RTOL_FINAL
-        assert relerr(g.get_points()[0], o.get_points()) < RTOL_FINAL
-        del g, o
+def north_star_errors(g, o):
+    """SURVEY.md §8(d) acceptance metrics of north_star, per pose / per point:
+    max rotation angle [rad], max |dt|/|t|, max |dX|/|X| between the HIP
+    solver's and the oracle's CURRENT parameters."""
+    P, oP = g.get_poses(), o.get_poses()
+    X, oX = g.get_points()[0], o.get_points()
+    ang, dt = pose_errors(P, oP)
+    dX = (np.linalg.norm(X - oX, axis=1) /
+          np.maximum(np.linalg.norm(oX, axis=1), 1e-300)).max()
+    return ang, dt, dX
+
+
+def assert_same_trajectory(rows, orows, rtol_cost=1e-7):
+    """Identical accept / reject decisions and lambda sequence, trial costs to
+    rtol_cost (relative; floored at 1e-12 of the starting cost, the roundoff
+    level a noise-free scene converges to)."""
+    assert len(rows) == len(orows)
+    floor = 1e-12 * abs(orows[0].cost)
+    for k, (a, b) in enumerate(zip(rows, orows)):
+        assert a.iteration_status == b.iteration_status, k
+        assert relerr(a.damping_term, b.damping_term) < 1e-12, k
+        assert abs(a.trial_cost - b.trial_cost) <= rtol_cost * abs(b.trial_cost) + floor, k
+        assert abs(a.cost - b.cost) <= rtol_cost * abs(b.cost) + floor, k
+
+
+def test_config_c2_to_convergence_matches_faithful_oracle(built):
+    """BASELINE config C2 (mono 200 / 50 k / 500 k) run until the solver's own
+    convergence test fires (reference :971-975), against the FAITHFUL oracle
+    (restated Eigen pivoted LDLT): same number of iterations, same status and
+    lambda sequence, and the north-star metrics per pose / point <= 1e-4."""
+    sc = scenes.config_scene("C2")
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    kw = dict(max_iter=80, thr_step=1e-9, thr_cost=1e-9)
+    rows, conv = g.solve(make_options(**kw))
+    orows, oconv = o.solve(O.make_options(**kw))
+    assert conv and oconv and len(rows) >= 25
+    assert_same_trajectory(rows, orows)
+    ang, dt, dX = north_star_errors(g, o)
+    assert ang <= RTOL_FINAL and dt <= RTOL_FINAL and dX <= RTOL_FINAL, (ang, dt, dX)
+    # and the fixed point is the ground truth of the noise-free scene
+    Xt = sc["X_true"] * 0.01
+    assert np.median(np.linalg.norm(g.get_points()[0] - Xt, axis=1)) < 1e-6
+
+
+@pytest.mark.parametrize("name,iters", [("C3", 16), ("C4", 14)])
+def test_config_c3_c4_trajectories_match_fast_oracle(name, iters, built):
+    """BASELINE configs C3 (stereo 500 / 200 k / 2 M) and C4 (stereo 1000 /
+    500 k / 5 M, the headline): >= 12 LM iterations against the oracle in
+    fast-solve mode (envelope LDL^T, cross-checked against the faithful
+    pivoted LDLT in tests/test_oracle_pins.py; the faithful dense factorisation
+    needs 17 s per C4 iteration).  Status / lambda sequences identical,
+    north-star metrics per pose / point <= 1e-4 after every batch."""
+    sc = scenes.config_scene(name)
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    o.set_fast_solve(True)
+    kw = dict(max_iter=iters, thr_step=0, thr_cost=0)
+    rows, _ = g.solve(make_options(**kw))
+    orows, _ = o.solve(O.make_options(**kw))
+    assert len(rows) == iters
+    assert_same_trajectory(rows, orows)
+    ang, dt, dX = north_star_errors(g, o)
+    assert ang <= RTOL_FINAL and dt <= RTOL_FINAL and dX <= RTOL_FINAL, (ang, dt, dX)
+    assert rows[-1].cost < 0.02 * rows[0].cost     # well past the first steps
 
 
 def test_config_c4_first_iteration_matches_oracle(built):
-    """The headline configuration (stereo 1000 / 500 k / 5 M) against the oracle:
-    one LM iteration (the oracle needs about 20 s for it, nearly all of it in the
-    reference-style dense LDLT of the 5970 x 5970 reduced system)."""
+    """The headline configuration (stereo 1000 / 500 k / 5 M) against the
+    FAITHFUL oracle: one LM iteration (about 20 s, nearly all of it in the
+    reference-style dense LDLT of the 5970 x 5970 reduced system); the longer
+    C4 trajectory is in test_config_c3_c4_trajectories_match_fast_oracle."""
     sc = scenes.config_scene("C4")
     pr = scenes.scaled_problem(sc)
     g, o = make_gpu(pr), O.Oracle(pr)
-    rows, _ = g.solve(O.make_options(max_iter=1, thr_step=0, thr_cost=0, cls=BaOptions))
+    rows, _ = g.solve(make_options(max_iter=1, thr_step=0, thr_cost=0))
     orows, _ = o.solve(O.make_options(max_iter=1, thr_step=0, thr_cost=0))
     assert rows[0].iteration_status == orows[0].iteration_status
     assert relerr(rows[0].trial_cost, orows[0].trial_cost) < 1e-8
     assert relerr(rows[0].model_change, orows[0].model_change) < 1e-7
-    assert relerr(g.get_poses(), o.get_poses()) < RTOL_FINAL
-    assert relerr(g.get_points()[0], o.get_points()) < RTOL_FINAL
+    ang, dt, dX = north_star_errors(g, o)
+    assert ang <= RTOL_FINAL and dt <= RTOL_FINAL and dX <= RTOL_FINAL, (ang, dt, dX)

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from bundle_adjustment_solver_amd import scenes
-from bundle_adjustment_solver_amd._lib import BaOptions
+from bundle_adjustment_solver_amd._lib import make_options
 from bundle_adjustment_solver_amd.solver import (BaProblem, Options,
                                                  PoseOnlyBundleAdjustmentSolver,
                                                  Summary)
@@ -23,9 +23,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def po_options(cls=None):
-    return O.make_options(max_iter=100, thr_step=1e-6, thr_cost=1e-6,
-                          huber=1.0, outlier=2.5, cls=cls)
+PO_KW = dict(max_iter=100, thr_step=1e-6, thr_cost=1e-6, huber=1.0, outlier=2.5)
+
+
+def po_options(product=False):
+    return make_options(**PO_KW) if product else O.make_options(**PO_KW)
 
 
 @pytest.mark.parametrize("n,seed,sigma", [(10_000, 2024, 0.0),
@@ -37,7 +39,7 @@ def test_matches_oracle(n, seed, sigma, built):
     g = BaProblem(0)
     res = g.pose_only_mono6(sc["X"], sc["uv"], sc["fx"], sc["fy"], sc["cx"],
                             sc["cy"], T12, np.ones(n, np.uint8),
-                            po_options(BaOptions), want_debug=True)
+                            po_options(True), want_debug=True)
     ref = O.pose_only_mono6(sc["X"], sc["uv"], sc["fx"], sc["fy"], sc["cx"],
                             sc["cy"], sc["T_init"], np.ones(n, np.uint8),
                             po_options())
@@ -100,7 +102,7 @@ def test_stereo_matches_oracle(n, seed, sigma, miss, built):
     res = g.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
                               to12(sc["T_lr"]), to12(sc["T_init"]),
                               np.ones(n, np.uint8), np.ones(n, np.uint8),
-                              po_options(BaOptions), want_debug=True)
+                              po_options(True), want_debug=True)
     ref = O.pose_only_stereo6(sc["X"], sc["uv"], sc["uv_right"], intr, intr,
                               sc["T_lr"], sc["T_init"], np.ones(n, np.uint8),
                               np.ones(n, np.uint8), po_options())

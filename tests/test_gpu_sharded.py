@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from bundle_adjustment_solver_amd import scenes
-from bundle_adjustment_solver_amd._lib import BaOptions
+from bundle_adjustment_solver_amd._lib import make_options
 from bundle_adjustment_solver_amd.solver import BaProblem
 from oracle import oracle_py as O
 
@@ -119,7 +119,7 @@ def test_nccl_world1_hook_matches_plain_solve(built):
     try:
         sc = scenes.synthetic_ba_scene(24, 1500, 5, True, seed=29)
         pr = scenes.scaled_problem(sc)
-        opt = O.make_options(max_iter=10, thr_step=0, thr_cost=0, cls=BaOptions)
+        opt = make_options(max_iter=10, thr_step=0, thr_cost=0)
         plain = make(pr)
         rows0, _ = plain.solve(opt)
         hooked = make(pr, stream=torch.cuda.current_stream().cuda_stream)

@@ -321,3 +321,77 @@ def test_stereo_pose_only_golden_vector():
     assert np.abs(r["T12"] - np.array(gold["T12"])).max() < 1e-6
     assert int(r["mask_l"].sum()) == gold["n_inlier_left"]
     assert int(r["mask_r"].sum()) == gold["n_inlier_right"]
+
+
+# --------------------------------------------------------------------------
+# fast-solve mode of the oracle (envelope LDL^T without pivoting): the test
+# shortcut that lets the BASELINE-size trajectories be followed for many
+# iterations.  It must agree with the restated Eigen pivoted LDLT.
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_fast_solve_matches_the_pivoted_ldlt(name, built):
+    """Same S, rhs -> x of the envelope LDL^T equals x of the reference-style
+    pivoted LDLT to <= 1e-9 (max-norm relative) on C1 (dense S) and on the full
+    C2 (banded S), at a large and at a small damping."""
+    pr = scenes.scaled_problem(scenes.config_scene(name))
+    o = O.Oracle(pr)
+    for lam in (100.0, 1e-3):
+        o.linearize(1.0)
+        o.damp_invert(lam)
+        o.schur()
+        o.set_fast_solve(False)
+        o.solve_reduced()
+        x_ref = o.get_xy()[0].copy()
+        o.set_fast_solve(True)
+        o.solve_reduced()
+        x_fast = o.get_xy()[0].copy()
+        assert np.abs(x_ref).max() > 0
+        assert np.abs(x_fast - x_ref).max() <= 1e-9 * np.abs(x_ref).max(), (name, lam)
+        S, rhs = o.get_S()
+        res = np.abs(S @ x_fast.reshape(-1) - rhs).max() / np.abs(rhs).max()
+        assert res < 1e-9
+
+
+def test_fast_solve_trajectory_equals_the_faithful_one(built):
+    """Whole LM loop on C1 and on a mono window scene: identical status and
+    lambda sequences, costs to 1e-9, final parameters to 1e-8."""
+    for sc in (scenes.test_ba_scene(),
+               scenes.synthetic_ba_scene(30, 1500, 10, False, seed=41)):
+        pr = scenes.scaled_problem(sc)
+        outs = []
+        for fast in (False, True):
+            o = O.Oracle(pr)
+            o.set_fast_solve(fast)
+            rows, conv = o.solve(O.make_options(max_iter=30, thr_step=1e-7,
+                                                thr_cost=1e-7))
+            outs.append((rows, conv, o.get_poses(), o.get_points()))
+        (ra, ca, Pa, Xa), (rb, cb, Pb, Xb) = outs
+        assert len(ra) == len(rb) and ca == cb
+        for a, b in zip(ra, rb):
+            assert a.iteration_status == b.iteration_status
+            assert a.damping_term == b.damping_term
+            # relative to the trial cost, floored at the roundoff level of the
+            # starting cost (noise-free scenes converge to ~1e-9 of it)
+            assert abs(a.trial_cost - b.trial_cost) <= 1e-9 * abs(a.trial_cost) \
+                + 1e-12 * ra[0].cost
+        assert np.abs(Pa - Pb).max() <= 1e-8 * np.abs(Pa).max()
+        assert np.abs(Xa - Xb).max() <= 1e-8 * np.abs(Xa).max()
+
+
+def test_fast_solve_zero_pivot_gives_zero_step(built):
+    """A pose without observations has a zero row / column in S: both solvers
+    return x_j = 0 for it (pseudo-inverse rule)."""
+    sc = scenes.synthetic_ba_scene(12, 60, 5, False, seed=5)
+    keep = sc["obs_pose"] != 11
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        sc[k] = sc[k][keep]
+    pr = scenes.scaled_problem(sc)
+    o = O.Oracle(pr)
+    o.linearize(1.0); o.damp_invert(2.0); o.schur()
+    xs = []
+    for fast in (False, True):
+        o.set_fast_solve(fast)
+        o.solve_reduced()
+        xs.append(o.get_xy()[0].copy())
+    assert (xs[0][-1] == 0).all() and (xs[1][-1] == 0).all()
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-9 * np.abs(xs[0]).max()

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bundle_adjustment_solver_amd import scenes
-from bundle_adjustment_solver_amd._lib import BaOptions
+from bundle_adjustment_solver_amd._lib import make_options
 from bundle_adjustment_solver_amd.solver import BaProblem
 from oracle import oracle_py as O
 
@@ -14,7 +14,7 @@ def free_bytes():
 
 sc = scenes.synthetic_ba_scene(30, 4000, 5, True, seed=3)
 pr = scenes.scaled_problem(sc)
-opt = O.make_options(max_iter=4, thr_step=0, thr_cost=0, cls=BaOptions)
+opt = make_options(max_iter=4, thr_step=0, thr_cost=0)
 
 def make(finalize=True):
     p = BaProblem(0)
