@@ -72,6 +72,36 @@ def pmc_traffic(kernel, config):
             os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))))
 
 
+DENSE_GRID_GB = {"C1": 0.021, "C2": 5.6, "C3": 57.0, "C4": 287.0}
+
+
+def dense_faithful_baseline(O, scenes, config, pr, huber):
+    """One LM iteration of the oracle with the reference's dense N x M block
+    grids allocated and re-zeroed (ba_oracle_set_dense_faithful).  C3 / C4: the
+    grids need 57 / 287 GB -> reported as not runnable, and the C2 figure is
+    measured instead so that the default (C4) line still carries one."""
+    out = {}
+    runnable = config if config in ("C1", "C2") else "C2"
+    if runnable != config:
+        out["note"] = ("%s: the reference layout needs %.0f GB of dense N x M "
+                       "block grids - not runnable; measured at C2 instead"
+                       % (config, DENSE_GRID_GB[config]))
+    if pr is None or runnable != config:
+        pr = scenes.scaled_problem(scenes.config_scene(runnable))
+    o = O.Oracle(pr)
+    o.set_dense_faithful(True)
+    t = time.perf_counter()
+    o.solve(O.make_options(max_iter=1, thr_step=-1.0, thr_cost=-1.0, huber=huber))
+    dt = time.perf_counter() - t
+    out.update({"config": runnable, "value": 1.0 / dt, "unit": "it/s", "cores": 1,
+                "kind": "port", "dense_grid_GB": DENSE_GRID_GB[runnable],
+                "sample": "1 LM iteration at %s with the four dense N x M grids "
+                          "allocated and re-zeroed, %.2f s; stage ms build/schur/"
+                          "solve/control = %s" % (runnable, dt, ", ".join(
+                              "%.0f" % v for v in o.stage_ms()))})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +111,11 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0,
                     help="shrink the config (debug only; result is then "
                          "labelled as such)")
+    ap.add_argument("--sigma", type=float, default=0.0,
+                    help="pixel noise of the synthetic measurements [px] "
+                         "(SURVEY.md 8d: the headline is 0, second run 0.5)")
+    ap.add_argument("--huber", type=float, default=1.0,
+                    help="threshold_huber_loss (solver units of 0.01 px)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -92,6 +127,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+
+    # native artefacts first, before anything initialises the GPU or the process
+    # group: rank 0 alone checks the source stamps (and rebuilds what is stale);
+    # the other ranks block in init_process_group / the barrier below until it
+    # has joined, so nobody loads a library that is being rewritten
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build(only_if_missing=True)
 
     import torch
     import torch.distributed as dist
@@ -111,15 +154,15 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
 
-    import __graft_entry__ as ge
-    ge.build(only_if_missing=True)
+    if world > 1:
+        dist.barrier()   # rank 0 has finished build()
     from bundle_adjustment_solver_amd import scenes
     from bundle_adjustment_solver_amd._lib import make_options
     from bundle_adjustment_solver_amd.solver import BaProblem
     from oracle import oracle_py as O
 
     t_gen = time.time()
-    sc = scenes.config_scene(args.config, args.scale)
+    sc = scenes.config_scene(args.config, args.scale, args.sigma)
     pr = scenes.scaled_problem(sc)
     t_gen = time.time() - t_gen
 
@@ -146,7 +189,7 @@ def main():
     M_glob = int((pr["pt_fixed"] == 0).sum())
     # the LM loop must not stop inside the timed region: thresholds < 0
     opt = make_options(max_iter=args.warmup + args.steps + 1, thr_step=-1.0,
-                         thr_cost=-1.0)
+                       thr_cost=-1.0, huber=args.huber)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -187,7 +230,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": WORKLOADS[args.config] +
-            ("" if args.scale == 1.0 else " (scaled x%g, debug)" % args.scale),
+            ("" if args.scale == 1.0 else " (scaled x%g, debug)" % args.scale) +
+            ("" if args.sigma == 0.0 else ", pixel noise sigma %g px" % args.sigma) +
+            ("" if args.huber == 1.0 else ", huber %g" % args.huber),
             "n_opt_poses": N, "n_opt_landmarks": M_glob,
             "n_observations": n_obs,
             "parallelism": ("landmark-shard x%d + all-reduce(S|rhs)" % world +
@@ -209,7 +254,8 @@ def main():
         p.get_stage_ms(reset=True)
         p.get_kernel_ms(reset=True)
         n_prof = min(5, max(1, args.steps))
-        opt2 = make_options(max_iter=n_prof, thr_step=-1.0, thr_cost=-1.0)
+        opt2 = make_options(max_iter=n_prof, thr_step=-1.0, thr_cost=-1.0,
+                            huber=args.huber)
         p.lm_begin(opt2)
         p.lm_iterate(n_prof)
         p.lm_sync()
@@ -281,7 +327,7 @@ def main():
         o = O.Oracle(pr)
         t = time.perf_counter()
         orows, _ = o.solve(O.make_options(max_iter=1, thr_step=-1.0,
-                                          thr_cost=-1.0))
+                                          thr_cost=-1.0, huber=args.huber))
         dt = time.perf_counter() - t
         result["cpu_baseline"] = {
             "value": 1.0 / dt, "unit": "it/s", "cores": 1, "kind": "port",
@@ -297,6 +343,13 @@ def main():
             result["cpu_baseline"]["first_iter_trial_cost_rel_diff"] = abs(
                 rows[0].trial_cost - orows[0].trial_cost) / abs(
                     orows[0].trial_cost)
+        del o
+        # SURVEY.md 8(d), second CPU figure: the reference's OWN storage (dense
+        # N x M grids of 6x3 / 3x6 blocks, re-zeroed by ResetStorageMatrices
+        # every iteration, reference :343-379).  Runnable at C1 (21 MB) and C2
+        # (5.6 GB) only.
+        result["cpu_baseline"]["dense_faithful"] = dense_faithful_baseline(
+            O, scenes, args.config, pr if args.scale == 1.0 else None, args.huber)
 
     if rank == 0:
         print(json.dumps(result))

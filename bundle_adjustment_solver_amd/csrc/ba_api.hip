@@ -261,6 +261,8 @@ void ba_destroy(ba_handle *h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->free_device();
+  for (hipEvent_t e : h->kt.pool) (void)hipEventDestroy(e);
+  h->kt.pool.clear();
   if (h->ev_ok)
     for (int k = 0; k <= ST_N; ++k) (void)hipEventDestroy(h->ev[k]);
   h->drop_graph();
@@ -558,8 +560,9 @@ int ba_finalize(ba_handle *h) {
         h->upload(&dd.tgt_src_ptr, sc.tgt_src_ptr) || h->upload(&dd.src_t, sc.src_t) ||
         h->upload(&dd.tgt_desc, sc.tgt_desc) || h->upload(&dd.back_desc, sc.back_desc) ||
         h->upload(&dd.row_desc, sc.row_desc) ||
-        h->dalloc(&dd.xc, (size_t)d.npad))
+        h->dalloc(&dd.xc, (size_t)d.npad) || h->dalloc(&dd.bad_pivots, (size_t)1))
       return -1;
+    HIP_TRY(hipMemset(dd.bad_pivots, 0, sizeof(int)));
     if (sc.fused_ok &&
         (h->upload(&dd.f_desc, sc.f_desc) || h->upload(&dd.f_pend, sc.f_pend) ||
          h->dalloc(&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * nb * nb)))
@@ -647,6 +650,7 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
   const int done_after = c.done;
   c.done = 0;
   if (push_ctrl(h)) return -1;
+  HIP_TRY(hipMemsetAsync(h->ddev.bad_pivots, 0, sizeof(int), h->stream));
   // previous_cost = EvaluateCurrentCost()   (reference :707)
   ba::launch_cost(h->d, 0, h->stream);
   ba::launch_scalars_cost_only(h->d, h->stream);
@@ -1026,6 +1030,17 @@ int ba_get_dense_info(ba_handle *h, double out4[4]) {
   out4[1] = h->sched.flops;
   out4[2] = (double)h->sched.nlev;
   out4[3] = (double)h->d.npad;
+  return 0;
+}
+
+int ba_get_dropped_pivots(ba_handle *h, int64_t *count, int reset) {
+  if (!h || !h->finalized || !count) return fail("ba_get_dropped_pivots: bad argument");
+  if (use_device(h)) return -1;
+  int v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, h->ddev.bad_pivots, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (reset) HIP_TRY(hipMemsetAsync(h->ddev.bad_pivots, 0, sizeof(int), h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *count = v;
   return 0;
 }
 

@@ -65,8 +65,10 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // triangle (r >= c) is the SPD tile and the strict upper part is 0; on exit the
 // lower triangle is L_T and the strict upper part is L_T^-T (its diagonal is
 // 1/L_cc and is not stored).  A non-positive pivot zeroes its column.
-__device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
+// Returns the number of non-positive pivots met (wave-uniform).
+__device__ __forceinline__ int tile16_potrf_inv(double g[4], int lane) {
   const int r = lane & 15, q = lane >> 4;
+  int nbad = 0;
   // Elimination with UNSCALED columns (LDL^T style): step c only needs 1/d_c
   // (v_rcp_f64 + 2 Newton steps) on its dependent chain
   //   G[r][c2] -= G[r][c] G[c2][c] / d_c.
@@ -79,6 +81,7 @@ __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
     const int cq = c & 3, cj = c >> 2;
     const double d = readlane_f64(g[cj], c + 16 * cq);
     const bool ok = d > 1e-300;
+    nbad += ok ? 0 : 1;
     const double ds = ok ? d : 1.0;
     double ri = __builtin_amdgcn_rcp(ds);
     ri = fma(fma(-ds, ri, 1.0), ri, ri);
@@ -111,6 +114,12 @@ __device__ __forceinline__ void tile16_potrf_inv(double g[4], int lane) {
     y = fma(fma(-sq, y, 1.0), y, y);
     g[j] = ok ? ((r == c) ? sq : g[j] * y) : 0.0;
   }
+  return nbad;
+}
+// dropped pivots are counted per handle (ba_get_dropped_pivots); the integer
+// atomic runs only when a factorisation actually meets one
+__device__ __forceinline__ void count_bad_pivots(int *bad, int n, int lane) {
+  if (bad && n > 0 && lane == 0) atomicAdd(bad, n);
 }
 
 #ifdef BA_DENSE_DBG
@@ -153,7 +162,8 @@ constexpr int kTailES = 17;
 template <int NPt, bool PAIR>
 __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int npad, int c0,
                                                    double *xc, double *x,
-                                                   const int *__restrict__ col_x, const int *done) {
+                                                   const int *__restrict__ col_x, const int *done,
+                                                   int *bad) {
   constexpr int nbt = 16 * NPt;
   static_assert(nbt <= kTailCols, "tail block does not fit the LDS image");
   static_assert(!PAIR || NPt >= 4, "a paired first level has two 32-column tiles");
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int 
         const int c = 4 * j + q;
         g[j] = (r >= c) ? Lb[(16 * p + c) * LS + 16 * p + r] : 0.0;
       }
-      tile16_potrf_inv(g, lane);
+      count_bad_pivots(bad, tile16_potrf_inv(g, lane), lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = 4 * j + q;
@@ -307,18 +317,18 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     if (fused) {                                                                            \
       BA_LAUNCH(K_CHOL_LEVEL, NS::k_chol_level, dim3(nt), dim3(256), s, L, ld, npad, t0,    \
-                dd.f_desc, dd.rows, dd.f_pend, dd.cbuf, Ldiag, done);                       \
+                dd.f_desc, dd.rows, dd.f_pend, dd.cbuf, Ldiag, done, bad);                       \
       continue;                                                                             \
     }                                                                                       \
     const int it0 = sc.item_ptr[l], ni = sc.item_ptr[l + 1] - it0;                          \
     if (split) {                                                                            \
-      BA_LAUNCH(K_CHOL_DIAG, NS::k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag, done); \
+      BA_LAUNCH(K_CHOL_DIAG, NS::k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag, done, bad); \
       if (ni > 0)                                                                           \
         BA_LAUNCH(K_CHOL_TRSM, NS::k_chol_trsm, dim3(ni), dim3(NS::NP * 64), s, L, ld,      \
                   row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);                       \
     } else {                                                                                \
       BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_diag_trsm, dim3(nt), dim3(256), s, L, ld,      \
-                npad, t0, dd.row_desc, dd.rows, Ldiag, done);                               \
+                npad, t0, dd.row_desc, dd.rows, Ldiag, done, bad);                              \
     }                                                                                       \
     const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0;                            \
     if (ng > 0)                                                                             \
@@ -327,13 +337,13 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
   }                                                                                         \
   if (tail_cols == 64)                                                                      \
     BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<4, false>), dim3(1), dim3(256), s, L, ld, npad,     \
-              tail_c0, dd.xc, x, dd.col_x, done);                                           \
+              tail_c0, dd.xc, x, dd.col_x, done, bad);                                        \
   if (tail_cols == 96 && !tail_pair)                                                        \
     BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<6, false>), dim3(1), dim3(256), s, L, ld, npad,     \
-              tail_c0, dd.xc, x, dd.col_x, done);                                           \
+              tail_c0, dd.xc, x, dd.col_x, done, bad);                                        \
   if (tail_cols == 96 && tail_pair)                                                         \
     BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<6, true>), dim3(1), dim3(256), s, L, ld, npad,      \
-              tail_c0, dd.xc, x, dd.col_x, done);                                           \
+              tail_c0, dd.xc, x, dd.col_x, done, bad);                                        \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back, dim3(nt), dim3(256), s, L, ld, npad, t0,        \
@@ -343,6 +353,7 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const int *done, const DenseSchedule &sc,
                         const DenseDev &dd, hipStream_t s) {
+  int *bad = dd.bad_pivots;
   const int row_limit = npad + 16;  // rows that carry data (rhs = row npad)
   // The fused one-launch-per-level path is opt-in (BA_DENSE_FUSED=1): on C4 it
   // measured no faster than the three-kernel path (886 vs 876 us per LM

@@ -217,6 +217,7 @@ struct DenseDev {
   double *cbuf = nullptr;  // n_contrib contribution tiles (NB x NB, column-major)
   int *col_x = nullptr;   // npad: column -> index into x (6*pose + r) or -1
   double *xc = nullptr;   // npad: solution in column order
+  int *bad_pivots = nullptr;  // device counter of non-positive pivots (or null)
   // BA_DENSE_FUSED / BA_DENSE_SPLIT / BA_DENSE_TAIL as found when the schedule was uploaded
   bool want_fused = false, want_split = false, want_tail = true;
   void read_env() {

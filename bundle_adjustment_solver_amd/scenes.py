@@ -198,15 +198,17 @@ CONFIGS = {
 }
 
 
-def config_scene(name, scale=1.0):
+def config_scene(name, scale=1.0, pixel_sigma=0.0):
     """Scene of a BASELINE.json config; scale<1 shrinks poses and landmarks
-    proportionally (parity-test sizes)."""
+    proportionally (parity-test sizes); pixel_sigma is the measurement noise in
+    pixels (0, and a second run at 0.5)."""
     if name == "C1":
-        return test_ba_scene()
+        return test_ba_scene(pixel_sigma=pixel_sigma)
     n_pose, n_pt, window, stereo, seed = CONFIGS[name]
     n_pose = max(window + 6, int(round(n_pose * scale)))
     n_pt = max(16, int(round(n_pt * scale)))
-    return synthetic_ba_scene(n_pose, n_pt, window, stereo, seed)
+    return synthetic_ba_scene(n_pose, n_pt, window, stereo, seed,
+                              pixel_sigma=pixel_sigma)
 
 
 def scaled_problem(scene):

@@ -44,28 +44,48 @@ def shard_observations(pr, owner, rank):
 
 class TorchExchange:
     """Owns the two exchange buffers as torch tensors, binds them into a
-    BaProblem and serves the all-reduce hook with torch.distributed."""
+    BaProblem and serves the all-reduce hook with torch.distributed.
+
+    The C ABI hands the hook the stream the problem's kernels run on
+    (include/ba_hip.h: "ordered on hip_stream"): the collective is issued with
+    THAT stream current (torch.cuda.ExternalStream), whatever stream the handle
+    uses — its own (the default) or one given through ba_set_stream."""
 
     def __init__(self, problem, dist, device, stage_host=False):
         import torch
+        self.torch = torch
         self.dist = dist
+        self.device = torch.device(device)
         # stage_host: all-reduce a host copy (a backend without device
         # collectives, e.g. gloo when several ranks rehearse on one card)
         self.stage_host = stage_host
         self.bufs = []
+        self._streams = {}
         for which in (0, 1):
             n = problem.reduce_buffer_size(which)
-            t = torch.zeros(n, dtype=torch.float64, device=device)
+            t = torch.zeros(n, dtype=torch.float64, device=self.device)
             problem.bind_reduce_buffer(which, t.data_ptr(), n)
             self.bufs.append(t)
         problem.set_allreduce(self.hook)
 
+    def _stream(self, ptr):
+        ptr = int(ptr or 0)
+        st = self._streams.get(ptr)
+        if st is None:
+            st = self.torch.cuda.ExternalStream(ptr, device=self.device)
+            self._streams[ptr] = st
+        return st
+
     def hook(self, which, ptr, n, stream):
-        # issued on torch's current stream == the stream the kernels run on
-        if self.stage_host:
-            h = self.bufs[which].cpu()
-            self.dist.all_reduce(h)
-            self.bufs[which].copy_(h)
-        else:
-            self.dist.all_reduce(self.bufs[which])
+        buf = self.bufs[which]
+        if int(ptr or 0) != buf.data_ptr() or n > buf.numel():
+            return -1   # the library is not using the bound buffer: refuse
+        with self.torch.cuda.stream(self._stream(stream)):
+            if self.stage_host:
+                h = buf.cpu()              # waits for the kernels on `stream`
+                self.dist.all_reduce(h)
+                buf.copy_(h)
+            else:
+                self.dist.all_reduce(buf)  # stream-ordered: RCCL waits on / is
+                #                            waited for by the current stream
         return 0

@@ -439,6 +439,15 @@ class BaProblem:
         return dict(fill=out[0], flops=out[1], levels=int(out[2]),
                     npad=int(out[3]))
 
+    def get_dropped_pivots(self, reset=False):
+        """Non-positive pivots met by the reduced-system Cholesky since lm_begin
+        (see include/ba_hip.h: where it differs from the reference's pivoted
+        LDLT)."""
+        v = C.c_int64(0)
+        check(self.lib.ba_get_dropped_pivots(self.h, C.byref(v), int(reset)),
+              "ba_get_dropped_pivots")
+        return int(v.value)
+
     def dense_spd_solve(self, A, b):
         A = np.ascontiguousarray(A, np.float64)
         b = np.ascontiguousarray(b, np.float64)
@@ -721,9 +730,8 @@ class FullBundleAdjustmentSolver:
         self._stream = stream
 
     # ---- finalize / solve ----
-    def FinalizeParameters(self):   # reference :182-206 (private there)
-        if self.is_parameter_finalized_:
-            return
+    def _host_arrays(self):
+        """The registered problem as C-ABI level arrays (host only, no GPU)."""
         if not self.camera_id_to_camera_map_ or not self.num_total_poses_ \
                 or not self.num_total_points_:
             raise RuntimeError("cameras, poses and points must be added "
@@ -752,6 +760,12 @@ class FullBundleAdjustmentSolver:
         else:
             ocam = opose = opt = np.zeros(0, np.int32)
             ouv = np.zeros((0, 2))
+        return intr, camT, T_jw, X, pf, qf, ocam, opose, opt, ouv
+
+    def FinalizeParameters(self):   # reference :182-206 (private there)
+        if self.is_parameter_finalized_:
+            return
+        intr, camT, T_jw, X, pf, qf, ocam, opose, opt, ouv = self._host_arrays()
         p = BaProblem(self.device)
         p.set_cameras(intr, camT)
         p.set_poses(T_jw, pf)
@@ -765,9 +779,35 @@ class FullBundleAdjustmentSolver:
         if self._allreduce is not None:
             p.set_allreduce(self._allreduce)
         self._problem = p
+        self._connectivity_input = (pf, qf, opose, opt)
         self.num_optimization_poses_ = int((pf == 0).sum())
         self.num_optimization_points_ = int((qf == 0).sum())
         self.is_parameter_finalized_ = True
+
+    def CheckPoseAndPointConnectivity(self):   # reference :310-341
+        """stderr warnings for an optimisable pose that observes fewer than 5
+        distinct points and for an optimisable point seen from fewer than 2
+        distinct poses (fixed ones count, reference :684-693).  Indices are the
+        optimisation indices (here: input order of the non-fixed entries; the
+        reference's are hash-order)."""
+        if self.is_parameter_finalized_:
+            pf, qf, opose, opt = self._connectivity_input
+        else:
+            _, _, _, _, pf, qf, _, opose, opt, _ = self._host_arrays()
+        n_pt = max(1, self.num_total_points_)
+        pairs = np.unique(opose.astype(np.int64) * n_pt + opt.astype(np.int64))
+        pts_of_pose = np.bincount(pairs // n_pt, minlength=self.num_total_poses_)
+        poses_of_pt = np.bincount(pairs % n_pt, minlength=self.num_total_points_)
+        j_opt = np.cumsum(pf == 0) - 1
+        i_opt = np.cumsum(qf == 0) - 1
+        for h in np.nonzero((pf == 0) & (pts_of_pose < 5))[0]:
+            sys.stderr.write(_yellow(
+                "%d-th pose: It might diverge because some frames have "
+                "insufficient related points." % j_opt[h]) + "\n")
+        for h in np.nonzero((qf == 0) & (poses_of_pt < 2))[0]:
+            sys.stderr.write(_yellow(
+                "%d-th point: It might diverge because some points have "
+                "insufficient related poses." % i_opt[h]) + "\n")
 
     def GetSolverStatistics(self):   # reference :208-239 (returns "", Q8)
         print("| Bundle Adjustment Statistics:")
@@ -808,6 +848,7 @@ class FullBundleAdjustmentSolver:
         self.FinalizeParameters()
         if self.verbose:
             self.GetSolverStatistics()
+        self.CheckPoseAndPointConnectivity()            # reference :703
         p = self._problem
         c_opt = options.to_c()
         c_opt.gauss_newton = 1 if self._use_gauss_newton(options) else 0

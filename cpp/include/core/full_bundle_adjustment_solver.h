@@ -86,6 +86,10 @@ class FullBundleAdjustmentSolver {
   void SetGaussNewton(bool on) { gauss_newton_ = on; }
 
  private:
+  // stderr warnings about weakly connected poses / points (reference
+  // core/full_bundle_adjustment_solver.cpp:310-341), called by Solve
+  void CheckPoseAndPointConnectivity();
+
   struct Observation {
     int camera_index;
     int pose_index;

@@ -3,6 +3,7 @@
 #include "core/full_bundle_adjustment_solver.h"
 
 #include <algorithm>
+#include <array>
 #include <stdexcept>
 
 #include "ba_hip.h"
@@ -209,6 +210,51 @@ std::string FullBundleAdjustmentSolver::GetSolverStatistics() const {  // :208-2
   return std::string();
 }
 
+void FullBundleAdjustmentSolver::CheckPoseAndPointConnectivity() {  // :310-341
+  static constexpr int kMinNumObservedPoints = 5;
+  static constexpr int kMinNumRelatedPoses = 2;
+  // distinct related points per pose (only "fewer than 5" matters: the first
+  // five distinct ids are kept) and distinct related poses per point (first id
+  // + "a second one exists"); fixed partners count (:684-693)
+  std::vector<std::array<int, kMinNumObservedPoints>> seen(poses_.size());
+  std::vector<int> n_seen(poses_.size(), 0), first_pose(points_.size(), -1);
+  std::vector<char> second_pose(points_.size(), 0);
+  for (const Observation &o : observations_) {
+    int &n = n_seen[o.pose_index];
+    if (n < kMinNumObservedPoints) {
+      auto &ids = seen[o.pose_index];
+      if (std::find(ids.begin(), ids.begin() + n, o.point_index) == ids.begin() + n) ids[n++] = o.point_index;
+    }
+    if (first_pose[o.point_index] < 0)
+      first_pose[o.point_index] = o.pose_index;
+    else if (first_pose[o.point_index] != o.pose_index)
+      second_pose[o.point_index] = 1;
+  }
+  // optimisation indices: input order of the non-fixed entries (the reference's
+  // are unordered_map iteration order)
+  int j_opt = 0;
+  for (size_t p = 0; p < poses_.size(); ++p) {
+    if (fixed_poses_.count(static_cast<int>(p))) continue;
+    if (n_seen[p] < kMinNumObservedPoints)
+      std::cerr << TEXT_YELLOW(std::to_string(j_opt) +
+                               "-th pose: It might diverge because some frames "
+                               "have insufficient related points.")
+                << std::endl;
+    ++j_opt;
+  }
+  int i_opt = 0;
+  for (size_t q = 0; q < points_.size(); ++q) {
+    if (fixed_points_.count(static_cast<int>(q))) continue;
+    const int num_related_pose = (first_pose[q] >= 0 ? 1 : 0) + (second_pose[q] ? 1 : 0);
+    if (num_related_pose < kMinNumRelatedPoses)
+      std::cerr << TEXT_YELLOW(std::to_string(i_opt) +
+                               "-th point: It might diverge because some "
+                               "points have insufficient related poses.")
+                << std::endl;
+    ++i_opt;
+  }
+}
+
 bool FullBundleAdjustmentSolver::Solve(Options options, Summary *summary) {  // :630-1044
   timer::StopWatch stopwatch("BundleAdjustmentSolver::Solve");
   stopwatch.Start();
@@ -220,6 +266,7 @@ bool FullBundleAdjustmentSolver::Solve(Options options, Summary *summary) {  // 
   }
   FinalizeParameters();
   if (verbose_) GetSolverStatistics();
+  CheckPoseAndPointConnectivity();  // :703
 
   ba_options o;
   o.threshold_step_size = options.convergence_handle.threshold_step_size;

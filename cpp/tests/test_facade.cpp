@@ -7,7 +7,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <iostream>
 #include <random>
+#include <sstream>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -146,7 +149,34 @@ int main() {
   options.convergence_handle.threshold_cost_change = 1e-6f;
   options.convergence_handle.threshold_step_size = 1e-6f;
   Summary summary;
-  EXPECT(ba_solver.Solve(options, &summary), "Solve returns true");
+  // CheckPoseAndPointConnectivity (reference :310-341, called at :703): the wall
+  // scene has landmarks no camera sees -> one "-th point" warning each on stderr,
+  // and every pose sees far more than 5 points -> no "-th pose" warning
+  std::stringstream captured;
+  std::streambuf *old_err = std::cerr.rdbuf(captured.rdbuf());
+  const bool solved = ba_solver.Solve(options, &summary);
+  std::cerr.rdbuf(old_err);
+  EXPECT(solved, "Solve returns true");
+  {
+    std::vector<char> seen_pt(true_points.size(), 0);
+    std::vector<int> poses_of_pt(true_points.size(), -1);
+    size_t weak_points = 0;
+    for (const Obs &o : obs) {
+      if (poses_of_pt[o.point] == -1) poses_of_pt[o.point] = o.pose;
+      else if (poses_of_pt[o.point] != o.pose) seen_pt[o.point] = 1;
+    }
+    for (size_t i = 0; i < true_points.size(); ++i) weak_points += !seen_pt[i];
+    const std::string text = captured.str();
+    size_t n_pt_warn = 0, n_pose_warn = 0, at = 0;
+    while ((at = text.find("-th point: It might diverge because some points have insufficient related poses.", at)) !=
+           std::string::npos) { ++n_pt_warn; ++at; }
+    at = 0;
+    while ((at = text.find("-th pose: It might diverge", at)) != std::string::npos) { ++n_pose_warn; ++at; }
+    EXPECT(weak_points > 0 && n_pt_warn == weak_points, "connectivity warnings: %zu points warned, %zu weak", n_pt_warn,
+           weak_points);
+    EXPECT(n_pose_warn == 0, "unexpected pose connectivity warnings: %zu", n_pose_warn);
+    std::printf("connectivity warnings: %zu weakly observed points reported on stderr\n", n_pt_warn);
+  }
   std::printf("%s\n", summary.BriefReport().c_str());
 
   ba_oracle_options oo{1e-6f, 1e-6f, 1.0f, 2.0f, 40, 100.0f, 0.33f, 3.0f};

@@ -192,6 +192,16 @@ int ba_get_kernel_ms(ba_handle *h, double *ms_out, int64_t *calls_out, int reset
  * matrix order }. */
 int ba_get_dense_info(ba_handle *h, double out4[4]);
 
+/* The reduced system is factorised by Cholesky WITHOUT pivoting; the
+ * reference uses Eigen's diagonally pivoted LDLT with a pseudo-inverted D
+ * (reference :905).  A non-positive pivot (<= 1e-300: a pose without
+ * observations, or an indefinite / rank-deficient S, e.g. no fixed pose and
+ * lambda at its floor) zeroes its column and solution component instead.
+ * `count` receives how many such pivots the factorisations met since
+ * ba_lm_begin (or since the last reset): 0 means the two factorisations agree
+ * up to roundoff. */
+int ba_get_dropped_pivots(ba_handle *h, int64_t *count, int reset);
+
 /* ---- dense SPD solve alone (tests / micro-bench of the MFMA kernel) ---- */
 /* Solves A x = b for symmetric positive (semi-)definite A (n x n row-major
  * host arrays) with the blocked fp64-MFMA Cholesky used for the reduced

@@ -688,6 +688,64 @@ def test_config_c3_c4_trajectories_match_fast_oracle(name, iters, built):
     assert rows[-1].cost < 0.02 * rows[0].cost     # well past the first steps
 
 
+def weighted_fraction(pr, huber, P=None, X=None):
+    """Share of observations on the weighted branch of reference :763-766
+    (|r_x| + |r_y| > threshold_huber_loss) at the given parameters (numpy)."""
+    P = pr["pose_T"] if P is None else P
+    X = pr["pt_X"] if X is None else X
+    T = P[pr["obs_pose"]]
+    Xij = np.einsum("nij,nj->ni", T[:, :9].reshape(-1, 3, 3), X[pr["obs_pt"]]) + T[:, 9:]
+    cT = pr["cam_T"][pr["obs_cam"]]
+    Xc = np.einsum("nij,nj->ni", cT[:, :9].reshape(-1, 3, 3), Xij) + cT[:, 9:]
+    K = pr["cam_intr"][pr["obs_cam"]]
+    r0 = K[:, 0] * Xc[:, 0] / Xc[:, 2] + K[:, 2] - pr["obs_uv"][:, 0]
+    r1 = K[:, 1] * Xc[:, 1] / Xc[:, 2] + K[:, 3] - pr["obs_uv"][:, 1]
+    return float((np.abs(r0) + np.abs(r1) > huber).mean())
+
+
+@pytest.mark.parametrize("huber", [0.05, 0.005])
+@pytest.mark.parametrize("kind", ["stereo", "mono"])
+def test_robust_branch_with_pixel_noise(kind, huber, built):
+    """The Huber-like weight w = thr / (|r_x| + |r_y|) (reference :763-768) under
+    pixel noise sigma = 0.5 px (SURVEY.md §8d second run): thresholds of 5 px
+    (0.05 in the solver's 0.01-px units: every observation weighted at the start,
+    none at the end) and 0.5 px (about 60 % still weighted at the optimum).
+    Stage blocks, reduced system and an LM trajectory with rejected steps."""
+    stereo = kind == "stereo"
+    sc = scenes.synthetic_ba_scene(40, 3000, 5 if stereo else 10, stereo,
+                                   seed=12 if stereo else 11, pixel_sigma=0.5)
+    pr = scenes.scaled_problem(sc)
+    assert weighted_fraction(pr, huber) > 0.9
+    g, o = make_gpu(pr), O.Oracle(pr)
+    lam = 0.7
+    o.linearize(huber); o.damp_invert(lam); o.schur()
+    g.stage_linearize(lam, huber); g.stage_schur()
+    for (a, b) in zip(g.get_A() + g.get_C(), o.get_A() + o.get_C()):
+        assert blockwise_relerr(a, b) < RTOL_BLOCK
+    pi, pj, W = g.get_pairs()
+    opi, opj, oW = o.get_pairs()
+    assert blockwise_relerr(W[np.lexsort((pj, pi))], oW[np.lexsort((opj, opi))]) < RTOL_BLOCK
+    S, rhs = g.get_S()
+    oS, orhs = o.get_S()
+    assert relerr(S, oS) < 1e-9 and relerr(rhs, orhs) < 1e-9
+    # the weight matters: the unweighted blocks are different
+    o.linearize(1.0); o.damp_invert(lam)
+    assert relerr(g.get_A()[0], o.get_A()[0]) > 1e-2
+    # trajectory from the start
+    g, o = make_gpu(pr), O.Oracle(pr)
+    kw = dict(max_iter=18, thr_step=0, thr_cost=0, huber=huber)
+    rows, _ = g.solve(make_options(**kw))
+    orows, _ = o.solve(O.make_options(**kw))
+    assert_same_trajectory(rows, orows)
+    ang, dt, dX = north_star_errors(g, o)
+    assert ang <= RTOL_FINAL and dt <= RTOL_FINAL and dX <= RTOL_FINAL, (ang, dt, dX)
+    f_end = weighted_fraction(pr, huber, g.get_poses(), g.get_points()[0])
+    if huber < 0.01:
+        assert f_end > 0.3          # the weighted branch is live at the optimum
+    else:
+        assert f_end < 0.05
+
+
 def test_config_c4_first_iteration_matches_oracle(built):
     """The headline configuration (stereo 1000 / 500 k / 5 M) against the
     FAITHFUL oracle: one LM iteration (about 20 s, nearly all of it in the
@@ -703,3 +761,24 @@ def test_config_c4_first_iteration_matches_oracle(built):
     assert relerr(rows[0].model_change, orows[0].model_change) < 1e-7
     ang, dt, dX = north_star_errors(g, o)
     assert ang <= RTOL_FINAL and dt <= RTOL_FINAL and dX <= RTOL_FINAL, (ang, dt, dX)
+
+
+def test_dropped_pivots_are_reported(built):
+    """The reduced system is factorised by Cholesky without pivoting (the
+    reference: Eigen's pivoted LDLT with pseudo-inverted D).  Where the two can
+    differ — a non-positive pivot — the library counts it: 0 on a regular
+    problem, 6 per factorisation for a pose without observations (zero row and
+    column of S; both solvers then return x_j = 0, test_edge_cases)."""
+    sc = scenes.synthetic_ba_scene(12, 60, 5, False, seed=5)
+    pr = scenes.scaled_problem(sc)
+    g = make_gpu(pr)
+    g.solve(make_options(max_iter=4, thr_step=0, thr_cost=0))
+    assert g.get_dropped_pivots() == 0
+    keep = sc["obs_pose"] != 11
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        sc[k] = sc[k][keep]
+    pr = scenes.scaled_problem(sc)
+    g = make_gpu(pr)
+    g.solve(make_options(max_iter=4, thr_step=0, thr_cost=0))
+    assert g.get_dropped_pivots() == 6 * 4
+    assert g.get_dropped_pivots(reset=True) == 24 and g.get_dropped_pivots() == 0

@@ -140,5 +140,176 @@ def test_nccl_world1_hook_matches_plain_solve(built):
             assert a.trial_cost == b.trial_cost     # bit-identical
         assert np.array_equal(plain.get_poses(), hooked.get_poses())
         assert np.array_equal(plain.get_points()[0], hooked.get_points()[0])
+        # the handle on ITS OWN stream (the default; no ba_set_stream): the hook
+        # must issue the collective on the stream the C ABI hands it, not on
+        # torch's current stream, or the all-reduce races k_schur_final / k_scatter
+        own = make(pr)
+        ex2 = TorchExchange(own, dist, torch.device("cuda", 0))
+        seen = set()
+        orig2 = ex2.hook
+
+        def recording(which, ptr, n, stream):
+            seen.add(stream)
+            return orig2(which, ptr, n, stream)
+        own.set_allreduce(recording)
+        rows2, _ = own.solve(opt)
+        assert seen and torch.cuda.current_stream().cuda_stream not in seen
+        assert [r.trial_cost for r in rows2] == [r.trial_cost for r in rows0]
+        assert np.array_equal(plain.get_poses(), own.get_poses())
+        assert np.array_equal(plain.get_points()[0], own.get_points()[0])
     finally:
         dist.destroy_process_group()
+
+
+def test_two_shard_lm_loop_in_one_process(built):
+    """The world > 1 LM loop of the library (k_scalars -> exchange 1 -> separate
+    k_control; non-direct k_schur_final + k_scatter with the two-stream overlap)
+    driven end to end: two shard handles on the one card, each on its own host
+    thread and its own stream, through ba_lm_begin / ba_lm_iterate; the
+    all-reduce hook meets the other shard at a barrier and sums the two bound
+    buffers.  Per iteration status / lambda / trial cost must equal the unsharded
+    run, the replicated poses must be bit-identical on both shards, and every
+    shard's owned points must match the unsharded result."""
+    import threading
+    import torch
+    sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=23, pixel_sigma=0.3)
+    pr = scenes.scaled_problem(sc)
+    n_it = 12
+    opt = make_options(max_iter=n_it, thr_step=0, thr_cost=0)
+    full = make(pr)
+    frows, _ = full.solve(opt)
+    world = 2
+    sh = [make(pr, r, world) for r in range(world)]
+    bufs = []
+    for s_ in sh:
+        per = []
+        for which in (0, 1):
+            n = s_.reduce_buffer_size(which)
+            t = torch.zeros(n, dtype=torch.float64, device="cuda")
+            s_.bind_reduce_buffer(which, t.data_ptr(), n)
+            per.append(t)
+        bufs.append(per)
+    barrier = threading.Barrier(world)
+    calls = [0, 0]
+
+    def make_hook(rank):
+        def hook(which, ptr, n, stream):
+            assert ptr == bufs[rank][which].data_ptr()
+            st = torch.cuda.ExternalStream(stream)
+            st.synchronize()                       # this shard's partial is complete
+            barrier.wait()
+            if rank == 0:
+                tot = bufs[0][which] + bufs[1][which]
+                bufs[0][which].copy_(tot)
+                bufs[1][which].copy_(tot)
+                torch.cuda.synchronize()
+            barrier.wait()
+            calls[rank] += 1
+            return 0
+        return hook
+
+    for r in range(world):
+        sh[r].set_allreduce(make_hook(r))
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            out[rank] = sh[rank].solve(opt)
+        except Exception as e:  # noqa
+            errs.append((rank, repr(e)))
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert calls[0] == calls[1] >= 2 * n_it + 1
+    for r in range(world):
+        rows, _ = out[r]
+        assert len(rows) == len(frows) == n_it
+        for k, (a, b) in enumerate(zip(rows, frows)):
+            assert a.iteration_status == b.iteration_status, (r, k)
+            assert abs(a.damping_term - b.damping_term) <= 1e-12 * b.damping_term
+            assert abs(a.trial_cost - b.trial_cost) <= 1e-11 * abs(b.trial_cost), (r, k)
+            assert abs(a.cost - b.cost) <= 1e-11 * abs(b.cost), (r, k)
+    P0, P1 = sh[0].get_poses(), sh[1].get_poses()
+    assert np.array_equal(P0, P1)                  # replicated solve: same bits
+    assert relerr(P0, full.get_poses()) < 1e-9
+    fX = full.get_points()[0]
+    owned = np.zeros(fX.shape[0], bool)
+    for r in range(world):
+        X, m = sh[r].get_points()
+        assert not (owned & m).any()
+        owned |= m
+        assert relerr(X[m], fX[m]) < 1e-9
+    assert owned.all()
+
+
+def _rank_worker(rank, world, port, q):
+    """Child process of test_two_rank_lm_loop_in_child_processes."""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import torch
+        import torch.distributed as dist
+        from bundle_adjustment_solver_amd.sharding import TorchExchange
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=23, pixel_sigma=0.3)
+            pr = scenes.scaled_problem(sc)
+            p = make(pr, rank, world)
+            ex = TorchExchange(p, dist, torch.device("cuda", 0), stage_host=True)
+            rows, _ = p.solve(make_options(max_iter=12, thr_step=0, thr_cost=0))
+            X, m = p.get_points()
+            q.put((rank, "ok", [(r.iteration_status, r.damping_term, r.trial_cost, r.cost)
+                                for r in rows], p.get_poses(), X, m))
+            del ex
+        finally:
+            dist.destroy_process_group()
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc(), None, None, None, None))
+
+
+def test_two_rank_lm_loop_in_child_processes(built):
+    """bench.py's N > 1 code path as an asserted test: two fresh processes (one
+    rank each) share the card, landmarks sharded by ba_set_shard, the exchange
+    through torch.distributed (gloo, staged through the host: the one-GPU box has
+    no second device for RCCL) and sharding.TorchExchange.  Both ranks must
+    reproduce the one-rank trajectory to 1e-11 and end with identical poses."""
+    import torch.multiprocessing as mp
+    sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=23, pixel_sigma=0.3)
+    pr = scenes.scaled_problem(sc)
+    full = make(pr)
+    frows, _ = full.solve(make_options(max_iter=12, thr_step=0, thr_cost=0))
+    fP, fX = full.get_poses(), full.get_points()[0]
+    full.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg, *_ in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+    for rank, _, rows, P, X, m in res:
+        assert len(rows) == len(frows) == 12
+        for k, ((st, lam, tc, c), b) in enumerate(zip(rows, frows)):
+            assert st == b.iteration_status, (rank, k)
+            assert abs(lam - b.damping_term) <= 1e-12 * b.damping_term
+            assert abs(tc - b.trial_cost) <= 1e-11 * abs(b.trial_cost), (rank, k)
+            assert abs(c - b.cost) <= 1e-11 * abs(b.cost), (rank, k)
+        assert relerr(P, fP) < 1e-9
+        assert relerr(X[m], fX[m]) < 1e-9
+    assert np.array_equal(res[0][3], res[1][3])        # identical replicated poses
+    assert (res[0][5] ^ res[1][5]).all()               # owned masks partition the points

@@ -170,3 +170,38 @@ def test_documents_cite_existing_profile_files():
         names = [c[:m.start()] + v + c[m.end():] for v in m.group(1).split(",")] if m else [c]
         for n in names:
             assert glob.glob(os.path.join(root, "profiles", n)), "missing profiles/" + n
+
+
+def test_connectivity_warnings(capsys):
+    """CheckPoseAndPointConnectivity (reference :310-341): an optimisable pose
+    with fewer than 5 distinct related points and an optimisable point with fewer
+    than 2 distinct related poses are reported on stderr; fixed entries are not,
+    and fixed partners count as related (reference :684-693)."""
+    s = FullBundleAdjustmentSolver()
+    s.AddCamera(0, Camera(525.0, 525.0, 320.0, 240.0))
+    s.AddCamera(1, Camera(525.0, 525.0, 320.0, 240.0))
+    hp = s.AddPoseArray(np.tile(np.eye(4), (4, 1, 1)))
+    hx = s.AddPointArray(np.random.default_rng(0).uniform(1, 2, (8, 3)))
+    s.MakePoseFixed(int(hp[0]))
+    s.MakePointFixed(int(hx[7]))
+    px = np.zeros((1, 2))
+    # poses 0 (fixed), 1, 2 see points 0..5; pose 3 sees points 0..3 only (4 < 5,
+    # twice each through the two cameras: still 4 distinct points)
+    for j in (0, 1, 2):
+        for i in range(6):
+            s.AddObservations(0, [hp[j]], [hx[i]], px)
+    for i in range(4):
+        s.AddObservations(0, [hp[3]], [hx[i]], px)
+        s.AddObservations(1, [hp[3]], [hx[i]], px)
+    # point 6: seen by pose 1 only (through both cameras: one related pose);
+    # point 7: never seen but FIXED -> no warning
+    s.AddObservations(0, [hp[1]], [hx[6]], px)
+    s.AddObservations(1, [hp[1]], [hx[6]], px)
+    capsys.readouterr()
+    s.CheckPoseAndPointConnectivity()
+    err = capsys.readouterr().err
+    # optimisation indices: input order of the non-fixed entries
+    assert "2-th pose: It might diverge because some frames have insufficient related points." in err
+    assert err.count("-th pose:") == 1
+    assert "6-th point: It might diverge because some points have insufficient related poses." in err
+    assert err.count("-th point:") == 1
