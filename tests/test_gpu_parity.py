@@ -782,3 +782,28 @@ def test_dropped_pivots_are_reported(built):
     g.solve(make_options(max_iter=4, thr_step=0, thr_cost=0))
     assert g.get_dropped_pivots() == 6 * 4
     assert g.get_dropped_pivots(reset=True) == 24 and g.get_dropped_pivots() == 0
+
+
+@pytest.mark.parametrize("stereo", [True, False])
+def test_gauge_free_problem_at_the_lambda_floor(stereo, built):
+    """No fixed pose and lambda at its floor of 1e-10 (reference :949): the
+    reduced system keeps the gauge freedom of the scene (mono: cond(S) ~ 1e13).
+    Un-pivoted Cholesky (HIP) and the reference-style pivoted LDLT (oracle) must
+    still agree: no dropped pivot, both residuals at roundoff, same trial cost."""
+    sc = scenes.synthetic_ba_scene(20, 600, 5 if stereo else 10, stereo, seed=31,
+                                   n_fixed=0, pose_noise=0.02, point_noise=0.05)
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    lam = 1e-10
+    o.linearize(1.0); o.damp_invert(lam); o.schur(); o.solve_reduced(); o.backsub()
+    g.stage_linearize(lam, 1.0); g.stage_schur()
+    g.get_dropped_pivots(reset=True)
+    g.stage_solve_reduced(); g.stage_backsub_update()
+    assert g.get_dropped_pivots() == 0
+    S, rhs = o.get_S()
+    x, _ = g.get_xy()
+    ox, _ = o.get_xy()
+    assert np.abs(S @ x.reshape(-1) - rhs).max() < 1e-12 * np.abs(rhs).max()
+    assert np.abs(S @ ox.reshape(-1) - rhs).max() < 1e-12 * np.abs(rhs).max()
+    o.backup(); o.update()
+    assert relerr(g.stage_scalars()[0], o.cost()) < 1e-5
