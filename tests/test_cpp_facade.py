@@ -45,14 +45,29 @@ def test_facade_builds_and_exports_reference_api():
 @pytest.mark.skipif(not os.path.exists("/root/reference/test/test_ba.cpp"),
                     reason="reference checkout not present (GPU box)")
 def test_reference_test_program_compiles_against_facade():
-    """The reference's own consumer, test/test_ba.cpp, compiles and links
-    UNCHANGED against cpp/include + libba_facade.so (nothing is copied: the
-    file is compiled where it lies, the binary stays in the ignored build dir
-    and does not travel to the GPU box)."""
+    """The reference's own consumers — test/test_ba.cpp, test/test_ba_refactor.cpp
+    and test/test_compare_ceres_vs_native.cpp — compile and link UNCHANGED
+    against cpp/include + libba_facade.so (nothing is copied: the files are
+    compiled where they lie, the binaries stay in the ignored build dir and do
+    not travel to the GPU box)."""
     _ensure_built()
     r = subprocess.run(["make", "-B", "dropin"], cwd=CPP, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0 and "drop-in OK" in r.stdout, r.stdout
+    assert r.returncode == 0 and r.stdout.count("drop-in OK") == 3, r.stdout
+    for name in ("test_ba.cpp", "test_ba_refactor.cpp", "test_compare_ceres_vs_native.cpp"):
+        assert "reference test/%s compiled and linked unchanged" % name in r.stdout
+
+
+def test_ceres_api_stand_in_on_cpu():
+    """cpp/build/test_ceres_shim: dual-number Jacobians vs finite differences,
+    AngleAxisRotatePoint vs so3Exp, exp/log round trips, the LM minimiser on the
+    seeded pose-only scene (the pieces of the independent fp64 check of config
+    C5; no GPU)."""
+    _ensure_built()
+    r = subprocess.run([os.path.join(CPP, "build", "test_ceres_shim")], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "CERES SHIM TEST PASSED" in r.stdout, r.stdout
 
 
 @pytest.mark.gpu
@@ -63,3 +78,18 @@ def test_cpp_facade_matches_oracle_on_gpu():
                        text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0 and "C++ FACADE TEST PASSED" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_pose_only_agrees_with_autodiff_lm_on_gpu():
+    """The "bundled Ceres check" of config C5: HIP pose-only solver (fp32,
+    analytic Gauss-Newton) vs fp64 automatic differentiation + Levenberg-
+    Marquardt (Ceres-API stand-in) on 10 k and 300 k points, with and without
+    pixel noise; poses agree to 1e-3 (cpp/tests/test_compare.cpp, the seeded
+    form of reference test/test_compare_ceres_vs_native.cpp:73-205)."""
+    _ensure_built()
+    r = subprocess.run([os.path.join(CPP, "build", "test_compare")], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0 and "COMPARE TEST PASSED" in r.stdout, r.stdout
