@@ -8,6 +8,7 @@
 #ifndef BA_FACADE_FULL_BUNDLE_ADJUSTMENT_SOLVER_H_
 #define BA_FACADE_FULL_BUNDLE_ADJUSTMENT_SOLVER_H_
 
+#include <cstdint>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -84,6 +85,19 @@ class FullBundleAdjustmentSolver {
   // itself never sets it (its Solve ignores options.solver_type, reference
   // :630-1044); FullBundleAdjustmentSolverRefactor does.
   void SetGaussNewton(bool on) { gauss_newton_ = on; }
+  // Multi-GPU (new): this process owns landmark shard `rank` of
+  // `world` (call before FinalizeParameters, with the SAME full problem
+  // registered on every rank) and provides the sum-all-reduce the library calls
+  // twice per LM iteration (ba_allreduce_fn of include/ba_hip.h; e.g.
+  // multi_gpu::RcclAllReduce::Hook of utility/rccl_allreduce.h).  After Solve
+  // every rank holds all poses; a rank's points are written back only for the
+  // landmarks it owns (OwnsPoint).
+  void SetShard(int rank, int world) {
+    shard_rank_ = rank;
+    shard_world_ = world;
+  }
+  void SetAllReduce(int (*fn)(void *, int, void *, int64_t, void *), void *user);
+  bool OwnsPoint(const _BA_Point *point) const;
 
  private:
   // stderr warnings about weakly connected poses / points (reference
@@ -103,6 +117,10 @@ class FullBundleAdjustmentSolver {
   bool gauss_newton_{false};
   int device_id_{0};
   ba_handle *handle_{nullptr};
+  int shard_rank_{0}, shard_world_{1};
+  int (*allreduce_fn_)(void *, int, void *, int64_t, void *){nullptr};
+  void *allreduce_user_{nullptr};
+  std::vector<uint8_t> owned_points_;  // filled by Solve (all ones on a single GPU)
 
   std::vector<_BA_Index> camera_ids_;
   std::vector<_BA_Camera> cameras_;  // scaled copies

@@ -41,6 +41,7 @@ FullBundleAdjustmentSolver::~FullBundleAdjustmentSolver() {
 void FullBundleAdjustmentSolver::Reset() {  // :44-70
   if (handle_) ba_destroy(handle_);
   handle_ = nullptr;
+  owned_points_.clear();
   is_parameter_finalized_ = false;
   camera_ids_.clear();
   cameras_.clear();
@@ -186,8 +187,22 @@ void FullBundleAdjustmentSolver::FinalizeParameters() {  // :182-206, :243-308, 
   }
   Check(ba_set_observations(handle_, static_cast<int64_t>(oc.size()), oc.data(), op.data(), oq.data(), uv.data()),
         "ba_set_observations");
+  if (shard_world_ > 1) Check(ba_set_shard(handle_, shard_rank_, shard_world_), "ba_set_shard");
   Check(ba_finalize(handle_), "ba_finalize");
+  if (allreduce_fn_) Check(ba_set_allreduce(handle_, allreduce_fn_, allreduce_user_), "ba_set_allreduce");
   is_parameter_finalized_ = true;
+}
+
+void FullBundleAdjustmentSolver::SetAllReduce(int (*fn)(void *, int, void *, int64_t, void *), void *user) {
+  allreduce_fn_ = fn;
+  allreduce_user_ = user;
+  if (is_parameter_finalized_) Check(ba_set_allreduce(handle_, fn, user), "ba_set_allreduce");
+}
+
+bool FullBundleAdjustmentSolver::OwnsPoint(const _BA_Point *point) const {
+  const auto it = point_index_.find(const_cast<_BA_Point *>(point));
+  if (it == point_index_.end()) return false;
+  return owned_points_.empty() || owned_points_[static_cast<size_t>(it->second)] != 0;
 }
 
 std::string FullBundleAdjustmentSolver::GetSolverStatistics() const {  // :208-239 (returns "")
@@ -285,7 +300,8 @@ bool FullBundleAdjustmentSolver::Solve(Options options, Summary *summary) {  // 
   // write back through the caller's pointers (:1011-1022)
   std::vector<double> T(12 * poses_.size()), X(3 * points_.size());
   Check(ba_get_poses(handle_, T.data()), "ba_get_poses");
-  Check(ba_get_points(handle_, X.data(), nullptr), "ba_get_points");
+  owned_points_.assign(points_.size(), 1);
+  Check(ba_get_points(handle_, X.data(), owned_points_.data()), "ba_get_points");
   for (size_t p = 0; p < poses_.size(); ++p) {
     if (fixed_poses_.count(static_cast<int>(p))) continue;
     _BA_Pose T_jw = Unpack12(&T[12 * p]);
@@ -294,7 +310,7 @@ bool FullBundleAdjustmentSolver::Solve(Options options, Summary *summary) {  // 
     *poses_[p] = T_jw.inverse();
   }
   for (size_t q = 0; q < points_.size(); ++q) {
-    if (fixed_points_.count(static_cast<int>(q))) continue;
+    if (fixed_points_.count(static_cast<int>(q)) || !owned_points_[q]) continue;
     X_[q] = _BA_Point(X[3 * q], X[3 * q + 1], X[3 * q + 2]);
     *points_[q] = X_[q] * inverse_scaler_;
   }

@@ -93,3 +93,19 @@ def test_pose_only_agrees_with_autodiff_lm_on_gpu():
                        timeout=600)
     print(r.stdout)
     assert r.returncode == 0 and "COMPARE TEST PASSED" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_allreduce_hook_world1_on_gpu(tmp_path):
+    """The C++ facade's N > 1 path (cpp/include/utility/rccl_allreduce.h: RCCL
+    loaded with dlopen, ncclAllReduce as the ba_allreduce_fn; FullBundle-
+    AdjustmentSolver::SetShard / SetAllReduce) on what a one-GPU box can run: a
+    world-size-1 communicator.  The exchange path must be bit-identical to the
+    plain solve (cpp/examples/multi_gpu_ba.cpp)."""
+    _ensure_built()
+    r = subprocess.run([os.path.join(CPP, "build", "multi_gpu_ba"), "0", "1",
+                        str(tmp_path / "rccl_id"), "0"], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "MULTI GPU EXAMPLE PASSED" in r.stdout, r.stdout
+    assert "bit-identical" in r.stdout
