@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libba_hip.so")
+# BA_HIP_LIB: developer override (a library built with in-kernel time stamps)
+LIB_PATH = os.environ.get("BA_HIP_LIB") or os.path.join(_HERE, "libba_hip.so")
 
 
 class BaOptions(C.Structure):

@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   int dbg_n = 0;
   DBG_STAMP()
 #endif
-  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * 18];
+  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * kWStride];  // compact {K, X_ij} records
   __shared__ __attribute__((aligned(16))) double Vs[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Cs[kSchurLandmarks * 6];
   __shared__ double Bs[kSchurLandmarks * 3];
@@ -858,14 +858,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   for (int ch = sd.chunk_begin; ch < sd.chunk_end; ++ch) {
     // registers -> LDS
     {
-      // compact record {K, X_ij} of pair p -> the first 12 doubles of its
-      // 18-double W image (K IS rows 0..2; X_ij is replaced by rows 3..5 below)
+      // compact records {K, X_ij} of the chunk's pairs, as they lie in HBM
       double2 *dst = (double2 *)Ws;
 #pragma unroll
       for (int k = 0; k < kSchurRW; ++k) {
         const int t = tid + k * kBlock;
-        const int pr = t / 6;
-        if (t < cd.np * 6) dst[pr * 9 + (t - pr * 6)] = rw[k];
+        if (t < cd.np * 6) dst[t] = rw[k];
       }
       double2 *cdst = (double2 *)Cs;
 #pragma unroll
@@ -898,15 +896,16 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
     DBG_STAMP()
     __syncthreads();
     DBG_STAMP()
-    // Rows 3..5 of W (= X_ij x columns of K) and V = W Cinv, from LDS: thread p
-    // does rows 0..2 of pair p, thread 128 + p rows 3..5 (the only reader of the
-    // X_ij it overwrites).  kBlock == 2 * kSchurPairs.
+    // V = W Cinv from LDS: thread p forms rows 0..2 (W rows 0..2 = K), thread
+    // 128 + p rows 3..5 (W rows 3..5 = X_ij x columns of K, formed in registers:
+    // the triple loop below rebuilds them from {K, X_ij} as well, so they are
+    // never stored).  kBlock == 2 * kSchurPairs.
     {
       static_assert(kBlock == 2 * kSchurPairs && (kSchurPairs & (kSchurPairs - 1)) == 0, "V phase mapping");
       const int pr = tid & (kSchurPairs - 1);
       const bool hi = tid >= kSchurPairs;  // wave-uniform
       if (pr < np) {
-        const double *kk = Ws + pr * 18;
+        const double *kk = Ws + pr * kWStride;
         const double *ci = Cs + (int)Pl[pr] * 6;
         double k9[9], c6[6], x3[3], wr[9];
 #pragma unroll
@@ -926,15 +925,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
 #pragma unroll
           for (int e = 0; e < 9; ++e) wr[e] = k9[e];
         }
-        double *wo = Ws + pr * 18 + 9, *vo = Vs + pr * 18 + (hi ? 9 : 0);
+        double *vo = Vs + pr * 18 + (hi ? 9 : 0);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const double w0 = wr[r * 3], w1 = wr[r * 3 + 1], w2 = wr[r * 3 + 2];
-          if (hi) {
-            wo[r * 3] = w0;
-            wo[r * 3 + 1] = w1;
-            wo[r * 3 + 2] = w2;
-          }
           vo[r * 3 + 0] = w0 * c6[0] + w1 * c6[1] + w2 * c6[2];
           vo[r * 3 + 1] = w0 * c6[1] + w1 * c6[3] + w2 * c6[4];
           vo[r * 3 + 2] = w0 * c6[2] + w1 * c6[4] + w2 * c6[5];
@@ -958,27 +952,36 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
         __builtin_amdgcn_sched_barrier(0);  // keep the read up here
         const uint32_t pp = pq >> 16, qq = pq & 0xffu;
         const double *vp = Vs + pp * 18 + h * 9;  // rows 3h..3h+2 of V
-        const double2 *wp = (const double2 *)(Ws + qq * 18);
+        // W_q from its compact record: rows 0..2 are K, rows 3..5 are X x K[:,m], so
+        //   sum_m v_m W[c][m]      = t_c           (c < 3),  t = K v
+        //   sum_m v_m W[3 + a][m]  = (X x t)_a
+        // 12 instead of 18 LDS doubles per triple; the loop is LDS-bandwidth bound
+        const double2 *wp = (const double2 *)(Ws + qq * kWStride);
         // diagonal triple (p == q): also B Cinv b of this pair (reference :864);
         // b is read unconditionally and masked (no divergent LDS reads)
         const double *bp = Bs + ((pq >> 8) & 0xffu) * 3;
         const double bm = (pp == qq) ? 1.0 : 0.0;
         const double b0 = bp[0] * bm, b1 = bp[1] * bm, b2 = bp[2] * bm;
-        double w[18];
+        double w[12];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < 6; ++k) {
           const double2 b2 = wp[k];
           w[2 * k] = b2.x;
           w[2 * k + 1] = b2.y;
         }
+        const double X0 = w[9], X1 = w[10], X2 = w[11];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const double v0 = vp[r * 3 + 0], v1 = vp[r * 3 + 1], v2 = vp[r * 3 + 2];
-#pragma unroll
-          for (int c = 0; c < 6; ++c)
-            acc[r * 6 + c] = fma(v2, w[c * 3 + 2],
-                                 fma(v1, w[c * 3 + 1],
-                                     fma(v0, w[c * 3 + 0], acc[r * 6 + c])));
+          const double t0 = fma(v2, w[2], fma(v1, w[1], v0 * w[0]));
+          const double t1 = fma(v2, w[5], fma(v1, w[4], v0 * w[3]));
+          const double t2 = fma(v2, w[8], fma(v1, w[7], v0 * w[6]));
+          acc[r * 6 + 0] += t0;
+          acc[r * 6 + 1] += t1;
+          acc[r * 6 + 2] += t2;
+          acc[r * 6 + 3] = fma(-X2, t1, fma(X1, t2, acc[r * 6 + 3]));
+          acc[r * 6 + 4] = fma(-X0, t2, fma(X2, t0, acc[r * 6 + 4]));
+          acc[r * 6 + 5] = fma(-X1, t0, fma(X0, t1, acc[r * 6 + 5]));
           racc[r] = fma(v2, b2, fma(v1, b1, fma(v0, b0, racc[r])));
         }
         pq = pqn;
