@@ -15,7 +15,7 @@
 #include "ba_plan.h"
 
 namespace ba {
-void launch_scalars_cost_only(const DevProblem &d, hipStream_t s);
+void launch_damp_invert_export(const DevProblem &d, hipStream_t s);
 }
 
 namespace {
@@ -48,6 +48,10 @@ struct ba_handle {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = true;
+  // the side stream holds work of the last enqueued iteration (pose-side
+  // linearisation at the trial point, reset of the factor tiles) that the main
+  // stream has not joined yet
+  bool side_pending = false;
   // one LM iteration captured as a hipGraph (single GPU, no timing) and
   // replayed by ba_lm_iterate instead of ~50 separate launches.  Opt-in
   // (BA_GRAPH=1): on ROCm 7.2 / MI355X the replay measured 2.5 % SLOWER than
@@ -144,43 +148,80 @@ int xchg(ba_handle *h, int which) {
   return 0;
 }
 
+// The main stream waits for the side stream's outstanding work (if any).
+void join_side(ba_handle *h) {
+  if (!h->side_pending) return;
+  (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);
+  h->side_pending = false;
+}
+
+// Linearisation at the `sel` parameters on the main stream (blocks of buffer
+// lcur ^ sel, cost partials as a by-product).
+void enqueue_linearize(ba_handle *h, int sel) {
+  const ba::DevProblem &d = h->d;
+  ba::launch_lin_poses(d, sel, h->stream);
+  ba::launch_lin_landmarks(d, sel, h->stream);
+  if (d.n_obs_lm < d.n_obs) ba::launch_cost(d, sel ? 2 : 0, d.n_obs_lm, h->stream);
+}
+
 // Enqueue one LM iteration (reference :709-1007) without host sync.
+// On entry the block buffer ctrl->lcur holds the linearisation at the accepted
+// parameters (made by ba_lm_begin or, as the trial-point linearisation, by the
+// previous iteration).  The iteration damps and inverts with the current lambda,
+// forms and solves the reduced system, back-substitutes, writes the trial
+// parameters, LINEARISES AT THE TRIAL POINT into the other block buffer — the
+// trial cost (reference :927) is the sum of the residual norms that pass computes
+// anyway — and takes the trust-region decision, which flips parameter and block
+// buffers together on acceptance.  Per iteration one pass over the observations
+// less than "cost at the trial point, then linearise again" (reference
+// :709-927), and a rejected step costs no second linearisation of the same point.
 int enqueue_iteration(ba_handle *h) {
   const ba::DevProblem &d = h->d;
   hipStream_t s = h->stream;
   ba::g_ktimer = h->timing ? &h->kt : nullptr;
-  // per-kernel / per-stage timing needs the serial order on one stream
-  const bool ov = h->overlap && !h->timing;
+  // per-kernel / per-stage timing needs the serial order on one stream; a captured
+  // graph cannot wait for an event of the previous replay
+  const bool ov = h->overlap && !h->timing && !h->use_graph;
+  const bool direct = !h->ar_fn;  // single GPU: S, rhs are placed in the dense matrix at once
   mark(h, 0);
-  if (ov) {
-    ba::launch_linearize_schur_overlapped(d, s, h->side_stream, h->ev_fork, h->ev_join,
-                                          /*direct=*/!h->ar_fn);
-    mark(h, 1);
-  } else {
-    ba::launch_linearize(d, s);
-    mark(h, 1);
-    ba::launch_schur(d, s);
-  }
-  mark(h, 2);
+  ba::launch_damp_invert(d, s);
+  const bool had_side = h->side_pending;
+  if (!had_side)
+    ba::launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, s);
+  ba::launch_schur_accumulate(d, s);
+  join_side(h);  // A_j, a_j of this point and the reset factor tiles come from the side stream
+  ba::launch_schur_final(d, direct, s);
+  mark(h, 1);
   if (xchg(h, 0)) return -1;
-  mark(h, 3);
-  if (!(ov && !h->ar_fn)) ba::launch_scatter(d, s);  // else placed by k_schur_final_direct
+  mark(h, 2);
+  if (!direct) ba::launch_scatter(d, s);
   ba::launch_dense_solve(d, h->sched, h->ddev, s);
+  mark(h, 3);
+  ba::launch_backsub_update(d, s);  // trial parameters, model terms, step norms
   mark(h, 4);
-  if (ov)
-    ba::launch_backsub_update_overlapped(d, s, h->side_stream, h->ev_fork, h->ev_join);
-  else
-    ba::launch_backsub_update(d, s);
+  if (ov) {
+    // pose side of the trial-point linearisation and the reset of the factor
+    // tiles: first needed by the NEXT iteration's k_schur_final
+    (void)hipEventRecord(h->ev_fork, s);
+    (void)hipStreamWaitEvent(h->side_stream, h->ev_fork, 0);
+    ba::launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, h->side_stream);
+    ba::launch_lin_poses(d, 1, h->side_stream);
+    (void)hipEventRecord(h->ev_join, h->side_stream);
+    h->side_pending = true;
+    ba::launch_lin_landmarks(d, 1, s);
+    if (d.n_obs_lm < d.n_obs) ba::launch_cost(d, 2, d.n_obs_lm, s);
+  } else {
+    enqueue_linearize(h, 1);
+  }
   mark(h, 5);
-  ba::launch_cost(d, 1, s);
   if (h->ar_fn) {
-    ba::launch_scalars(d, s);
+    ba::launch_scalars(d, 1, s);
     mark(h, 6);
     if (xchg(h, 1)) return -1;
     mark(h, 7);
     ba::launch_control(d, s);
   } else {  // nothing to exchange: the reduction workgroup also takes the LM decision
-    ba::launch_scalars_and_control(d, s);
+    ba::launch_scalars_and_control(d, 1, s);
     mark(h, 6);
     mark(h, 7);
   }
@@ -189,8 +230,8 @@ int enqueue_iteration(ba_handle *h) {
   if (h->timing) {
     HIP_TRY(hipStreamSynchronize(s));
     h->kt.collect();
-    static const int stage_of[8] = {ST_BUILD, ST_SCHUR, ST_XCHG,  ST_SOLVE,
-                                    ST_BACKSUB, ST_COST, ST_XCHG, ST_CTRL};
+    static const int stage_of[8] = {ST_SCHUR, ST_XCHG, ST_SOLVE, ST_BACKSUB,
+                                    ST_BUILD, ST_CTRL, ST_XCHG, ST_CTRL};
     for (int k = 0; k < 8; ++k) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, h->ev[k], h->ev[k + 1]) == hipSuccess)
@@ -487,17 +528,25 @@ int ba_finalize(ba_handle *h) {
   if (h->dalloc(&d.spart2, (size_t)d.n_slot * ba::kSlotStride)) return -1;
 
   // per-iteration storage
-  if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.b, (size_t)pl.M * 3) ||
-      h->dalloc(&d.Cinv, (size_t)pl.M * 6) ||
-      h->dalloc(&d.W, (size_t)pl.P * ba::kWStride) ||
-      h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) || h->dalloc(&d.A, (size_t)pl.N * 36) ||
-      h->dalloc(&d.a, (size_t)pl.N * 6) ||
+  for (int k = 0; k < 2; ++k) {
+    if (h->dalloc(&d.Cu[k], (size_t)pl.M * 6) || h->dalloc(&d.b[k], (size_t)pl.M * 3) ||
+        h->dalloc(&d.W[k], (size_t)pl.P * ba::kWStride) || h->dalloc(&d.A[k], (size_t)pl.N * 36) ||
+        h->dalloc(&d.a[k], (size_t)pl.N * 6))
+      return -1;
+    HIP_TRY(hipMemset(d.W[k], 0, std::max<size_t>(1, (size_t)pl.P * ba::kWStride) * sizeof(double)));
+    HIP_TRY(hipMemset(d.A[k], 0, std::max<size_t>(1, (size_t)pl.N * 36) * sizeof(double)));
+    HIP_TRY(hipMemset(d.a[k], 0, std::max<size_t>(1, (size_t)pl.N * 6) * sizeof(double)));
+  }
+  d.n_obs_lm = pl.M > 0 ? pl.lm_obs_ptr[pl.M] : 0;
+  if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.Cinv, (size_t)pl.M * 6) ||
+      h->dalloc(&d.lin_cost_part, (size_t)std::max(1, d.n_bchunk)) ||
+      h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) ||
       h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
       h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
       h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_bchunk) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
       h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
     return -1;
-  HIP_TRY(hipMemset(d.W, 0, std::max<size_t>(1, (size_t)pl.P * ba::kWStride) * sizeof(double)));
+  HIP_TRY(hipMemset(d.lin_cost_part, 0, (size_t)std::max(1, d.n_bchunk) * sizeof(double)));
   HIP_TRY(hipMemset(d.x, 0, ((size_t)pl.N * 6 + 64) * sizeof(double)));
   HIP_TRY(hipMemset(d.y, 0, std::max<size_t>(1, (size_t)pl.M * 3) * sizeof(double)));
   HIP_TRY(hipMemset(d.cost_part, 0, ba::kCostGrid * sizeof(double)));
@@ -633,7 +682,8 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
     h->d.log = nl;
     h->d.log_cap = opt->max_num_iterations;
   }
-  if (pull_ctrl(h)) return -1;  // keep `cur`
+  join_side(h);
+  if (pull_ctrl(h)) return -1;  // keep `cur` and `lcur`
   ba::DevCtrl &c = h->hc;
   c.lambda = (double)opt->initial_lambda;
   c.huber = (double)opt->threshold_huber_loss;
@@ -651,9 +701,10 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
   c.done = 0;
   if (push_ctrl(h)) return -1;
   HIP_TRY(hipMemsetAsync(h->ddev.bad_pivots, 0, sizeof(int), h->stream));
-  // previous_cost = EvaluateCurrentCost()   (reference :707)
-  ba::launch_cost(h->d, 0, h->stream);
-  ba::launch_scalars_cost_only(h->d, h->stream);
+  // first linearisation, at the starting point; previous_cost =
+  // EvaluateCurrentCost() (reference :707) is the sum of its residual norms
+  enqueue_linearize(h, 0);
+  ba::launch_scalars_cost_only(h->d, 1, h->stream);
   if (xchg(h, 1)) return -1;
   ba::launch_init_ctrl_cost(h->d, h->stream);
   if (done_after) {
@@ -705,6 +756,8 @@ int ba_lm_sync(ba_handle *h, ba_iter_info *out, int cap, int *n_iter,
                int *converged) {
   if (!h || !h->lm_begun) return fail("ba_lm_sync: call ba_lm_begin first");
   if (use_device(h)) return -1;
+  if (h->side_pending) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // (stays pending: the
+  //   next iteration joins it again, which is harmless)
   if (pull_ctrl(h)) return -1;
   const int n = h->hc.iter;
   if (n_iter) *n_iter = n;
@@ -743,8 +796,9 @@ int ba_stage_cost(ba_handle *h, double *cost) {
   if (pull_ctrl(h)) return -1;
   h->hc.done = 0;
   if (push_ctrl(h)) return -1;
-  ba::launch_cost(h->d, 0, h->stream);
-  ba::launch_scalars_cost_only(h->d, h->stream);
+  join_side(h);
+  ba::launch_cost(h->d, 0, 0, h->stream);
+  ba::launch_scalars_cost_only(h->d, 0, h->stream);
   if (xchg(h, 1)) return -1;
   HIP_TRY(hipMemcpyAsync(cost, h->d.scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -759,7 +813,9 @@ int ba_stage_linearize(ba_handle *h, double lambda, double huber) {
   h->hc.lambda = lambda;
   h->hc.huber = huber;
   if (push_ctrl(h)) return -1;
-  ba::launch_linearize(h->d, h->stream);
+  join_side(h);
+  enqueue_linearize(h, 0);
+  ba::launch_damp_invert(h->d, h->stream);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -768,7 +824,8 @@ int ba_stage_linearize(ba_handle *h, double lambda, double huber) {
 int ba_stage_schur(ba_handle *h) {
   if (!h || !h->finalized) return fail("ba_stage_schur: not finalized");
   if (use_device(h)) return -1;
-  ba::launch_schur(h->d, h->stream);
+  join_side(h);
+  ba::launch_schur(h->d, /*direct=*/false, /*with_init=*/true, h->stream);
   if (xchg(h, 0)) return -1;
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
@@ -798,8 +855,8 @@ int ba_stage_scalars(ba_handle *h, double *trial_cost, double *model_change,
                      double *pose_step_sum, double *point_step_sum) {
   if (!h || !h->finalized) return fail("ba_stage_scalars: not finalized");
   if (use_device(h)) return -1;
-  ba::launch_cost(h->d, 1, h->stream);
-  ba::launch_scalars(h->d, h->stream);
+  ba::launch_cost(h->d, 1, 0, h->stream);
+  ba::launch_scalars(h->d, 0, h->stream);
   if (xchg(h, 1)) return -1;
   double sc[4], pp[2];
   HIP_TRY(hipMemcpyAsync(sc, h->d.scal, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
@@ -878,9 +935,18 @@ int ba_get_points(ba_handle *h, double *X3, uint8_t *owned_mask) {
 int ba_get_A(ba_handle *h, double *A36, double *a6) {
   if (!h || !h->finalized) return fail("ba_get_A: not finalized");
   if (use_device(h)) return -1;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if (A36) HIP_TRY(hipMemcpy(A36, h->d.A, (size_t)h->plan.N * 36 * sizeof(double), hipMemcpyDeviceToHost));
-  if (a6) HIP_TRY(hipMemcpy(a6, h->d.a, (size_t)h->plan.N * 6 * sizeof(double), hipMemcpyDeviceToHost));
+  join_side(h);
+  if (pull_ctrl(h)) return -1;  // synchronises the stream
+  const int lb = h->hc.lcur;
+  if (A36) {
+    HIP_TRY(hipMemcpy(A36, h->d.A[lb], (size_t)h->plan.N * 36 * sizeof(double), hipMemcpyDeviceToHost));
+    // the device keeps A_j undamped and scales the diagonal where it reads it
+    // (reference :833-844): the same scaling here
+    const double lp1 = 1.0 + h->hc.lambda;
+    for (int j = 0; j < h->plan.N; ++j)
+      for (int r = 0; r < 6; ++r) A36[(size_t)j * 36 + r * 7] *= lp1;
+  }
+  if (a6) HIP_TRY(hipMemcpy(a6, h->d.a[lb], (size_t)h->plan.N * 6 * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -907,7 +973,10 @@ static int get_sym_vec(ba_handle *h, const double *dS6, const double *dV3,
 int ba_get_C(ba_handle *h, double *C9, double *b3) {
   if (!h || !h->finalized) return fail("ba_get_C: not finalized");
   if (use_device(h)) return -1;
-  return get_sym_vec(h, h->d.Cd, h->d.b, C9, b3);
+  join_side(h);
+  if (pull_ctrl(h)) return -1;
+  ba::launch_damp_invert_export(h->d, h->stream);  // damped C_i of the current block buffer and lambda
+  return get_sym_vec(h, h->d.Cd, h->d.b[h->hc.lcur], C9, b3);
 }
 
 int ba_get_Cinv(ba_handle *h, double *Cinv9, double *Cinvb3) {
@@ -916,8 +985,9 @@ int ba_get_Cinv(ba_handle *h, double *Cinv9, double *Cinvb3) {
   // Cinv_i b_i is not stored on the device (k_backsub_update forms it): same expression here
   const ba::Plan &pl = h->plan;
   std::vector<double> s6, b3;
+  if (pull_ctrl(h)) return -1;
   if (download(s6, h->d.Cinv, (size_t)pl.M * 6, h->stream)) return -1;
-  if (download(b3, h->d.b, (size_t)pl.M * 3, h->stream)) return -1;
+  if (download(b3, h->d.b[h->hc.lcur], (size_t)pl.M * 3, h->stream)) return -1;
   for (int i = 0; i < pl.M; ++i) {
     const int g = pl.iopt_of_user[pl.pt_user_of_int[i]];
     const double *ci = &s6[(size_t)i * 6], *b = &b3[(size_t)i * 3];
@@ -941,11 +1011,11 @@ int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18) {
     if (pair_j) pair_j[p] = pl.pair_pose[p];
   }
   if (W18) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (pull_ctrl(h)) return -1;  // synchronises the stream
     // the device keeps B_ji compact ({K, X_ij}, ba_device.h kWStride): expand
     std::vector<double> w12((size_t)pl.P * ba::kWStride);
     if (pl.P > 0)
-      HIP_TRY(hipMemcpy(w12.data(), h->d.W, w12.size() * sizeof(double), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(w12.data(), h->d.W[h->hc.lcur], w12.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int64_t p = 0; p < pl.P; ++p) {
       const double *k = &w12[(size_t)p * ba::kWStride];
       double *W = W18 + (size_t)p * 18;
@@ -1010,7 +1080,7 @@ const char *ba_kernel_name(int id) {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
       "k_schur_lds", "k_schur_partial", "k_schur_final", "k_scatter",
       "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_chol_diag_trsm", "k_chol_tail", "k_backsub_update",
-      "k_pose_update", "k_scalars", "k_control"};
+      "k_pose_update", "k_scalars", "k_control", "k_damp_invert"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
 }
 

@@ -29,7 +29,13 @@ struct DevCtrl {
   int converged;
   int max_iter;
   int gn;         // 1: plain Gauss-Newton (always accept, lambda fixed)
-  int pad_[2];
+  int lcur;       // which block buffer holds the linearisation at the accepted parameters
+  // Parameter / block buffers of the TRIAL point of the iteration in flight,
+  // written by k_pose_update before the trial-point linearisation starts.  The
+  // pose side of that linearisation runs on the side stream and may execute after
+  // the control step has flipped cur / lcur: it must not derive "trial" from them.
+  int tcur, tlcur;
+  int pad_;
 };
 
 struct DevIterRec {  // layout-identical to ba_iter_info
@@ -95,19 +101,29 @@ struct DevProblem {
   int64_t *blk_contrib_ptr;
   int32_t *contrib_slot;
   double *spart2;  // n_slot*kSlotStride slot partial sums (36 of S + 6 of rhs)
-  // per-iteration blocks
-  double *Cd;      // M*6   damped C_i upper (00 01 02 11 12 22)
-  double *b;       // M*3
-  double *Cinv;    // M*6   symmetric inverse upper
-  double *W;       // P*kWStride  compact B_ji (see kWStride)
+  // Linearisation blocks: TWO buffers each, selected by ctrl->lcur.  Every LM
+  // iteration linearises at its TRIAL point into the other buffer (the trial cost
+  // is a by-product of that pass: no separate cost kernel); accepting the step
+  // flips lcur together with cur, rejecting it keeps the old blocks, which are
+  // still the linearisation at the accepted point (reference :943-953 only
+  // changes lambda then).  The blocks are stored UNDAMPED; the (1 + lambda)
+  // scaling of the diagonals (reference :833-852) is applied where they are read.
+  double *Cu[2];   // M*6   C_i upper (00 01 02 11 12 22), undamped
+  double *b[2];    // M*3
+  double *W[2];    // P*kWStride  compact B_ji (see kWStride)
+  double *A[2];    // N*36  full (mirrored), undamped
+  double *a[2];    // N*6
+  double *Cinv;    // M*6   inverse of the damped C_i (k_damp_invert, after the control step)
+  double *Cd;      // M*6   damped C_i: written only for the readers (ba_get_C)
   double *Apart;   // n_achunk*27
-  double *A;       // N*36  damped, full
-  double *a;       // N*6
   double *spart;   // n_tchunk*kSlotStride
   double *x;       // 6N
   double *y;       // M*3
   // scalar reductions
-  double *cost_part;   // kCostGrid
+  double *cost_part;   // kCostGrid (k_cost: stage API, observations of fixed landmarks)
+  double *lin_cost_part;  // n_bchunk: sum of residual norms per k_lin_landmarks workgroup
+  int64_t n_obs_lm;    // observations of optimisable landmarks = the first n_obs_lm of the
+                       // landmark-major list (k_lin_landmarks sees exactly these)
   double *lm_part;     // kLmGrid*2 : model (landmark side), sum |y|
   double *pose_part;   // [0..1] totals, then kPoseGrid*2 block partials:
                        // model (pose side), sum |x|
@@ -151,7 +167,7 @@ enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
   K_SCHUR_LDS, K_SCHUR_PARTIAL, K_SCHUR_FINAL, K_SCATTER,
   K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_CHOL_DIAG_TRSM, K_CHOL_TAIL, K_BACKSUB_UPDATE,
-  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_COUNT
+  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_DAMP_INVERT, K_COUNT
 };
 struct KernelTimer {
   bool on = false;
@@ -181,22 +197,27 @@ extern thread_local KernelTimer *g_ktimer;
 #define BA_KEEP_S(x) asm volatile("" ::"s"(x))
 
 // ---- launchers (ba_kernels.hip) ----
-// sel: 0 = accepted parameters, 1 = trial parameters
-void launch_cost(const DevProblem &d, int sel, hipStream_t s);
-void launch_linearize(const DevProblem &d, hipStream_t s);
-void launch_schur(const DevProblem &d, hipStream_t s);
-// two-stream forms of linearize+schur and backsub+update (see ba_kernels.hip)
-// direct: single GPU, S and rhs are also placed in the dense matrix (no k_scatter)
-void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
-                                       hipStream_t s2, hipEvent_t fork,
-                                       hipEvent_t join, bool direct);
-void launch_backsub_update_overlapped(const DevProblem &d, hipStream_t s,
-                                      hipStream_t s2, hipEvent_t fork,
-                                      hipEvent_t join);
+// sel: 0 = accepted parameters (block buffer lcur), 1 = trial parameters (the
+// other block buffer)
+// k_cost over the observations [begin, n_obs) of the landmark-major list
+void launch_cost(const DevProblem &d, int sel, int64_t begin, hipStream_t s);
+// pose side (A_j, a_j) and landmark side (C_i, b_i, W_ji + the cost partials) of
+// the linearisation at the `sel` parameters
+void launch_lin_poses(const DevProblem &d, int sel, hipStream_t s);
+void launch_lin_landmarks(const DevProblem &d, int sel, hipStream_t s);
+void launch_damp_invert(const DevProblem &d, hipStream_t s);
+// dense_init + Schur accumulation + finalisation; direct: single GPU, S and rhs are
+// also placed in the dense matrix (no k_scatter); with_init: also reset the factor tiles
+void launch_schur(const DevProblem &d, bool direct, bool with_init, hipStream_t s);
+void launch_schur_accumulate(const DevProblem &d, hipStream_t s);
+void launch_schur_final(const DevProblem &d, bool direct, hipStream_t s);
 void launch_backsub_update(const DevProblem &d, hipStream_t s);
 void launch_scatter(const DevProblem &d, hipStream_t s);
-void launch_scalars(const DevProblem &d, hipStream_t s);
-void launch_scalars_and_control(const DevProblem &d, hipStream_t s);  // single GPU
+// cost_src: 0 = the k_cost partials only (stage API), 1 = the k_lin_landmarks
+// partials (+ the k_cost partials of fixed-landmark observations, if any)
+void launch_scalars_cost_only(const DevProblem &d, int cost_src, hipStream_t s);
+void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s);
+void launch_scalars_and_control(const DevProblem &d, int cost_src, hipStream_t s);  // single GPU
 void launch_control(const DevProblem &d, hipStream_t s);
 void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s);
 

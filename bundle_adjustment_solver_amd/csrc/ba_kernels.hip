@@ -1,10 +1,12 @@
 // ba_kernels.hip — gfx950 kernels of the full-BA LM iteration.
 //
 // Stage map (reference core/full_bundle_adjustment_solver.cpp):
-//   k_cost                 :381-433   sum of residual norms
-//   k_lin_landmarks        :716-831 (landmark side: C_i, b_i, W_ji)
-//                          + :846-856 (damp, 3x3 LDLT pseudo-inverse, Cinv b)
-//   k_lin_poses/_finalize  :716-810 (pose side: A_j, a_j) + :833-844 (damp)
+//   k_cost                 :381-433   sum of residual norms (stage API; fixed landmarks)
+//   k_lin_landmarks        :716-831 (landmark side: C_i, b_i, W_ji) and, as a
+//                          by-product, :381-433 the cost at the same parameters
+//   k_damp_invert          :846-856 (damp, 3x3 LDLT pseudo-inverse)
+//   k_lin_poses/_finalize  :716-810 (pose side: A_j, a_j; damping :833-844 is
+//                          applied where A_j is read)
 //   k_rhs_partial/_final   :864,:887 rhs_j = a_j - sum_i B_ji (Cinv_i b_i)
 //   k_schur_lds/_partial/_final :859-885  S_jk = d_jk A_j - sum_i V_ji W_ki^T,
 //                          V_ji = W_ji Cinv_i formed in LDS, never stored
@@ -375,12 +377,12 @@ struct ObsRec<false> {
   }
 
 template <bool LDSCAM, bool SLIM>
-__global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
+__global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel, int64_t begin) {
   __shared__ double sm[4];
   __shared__ double cams_s[kCamLds * 16];
   if (LDSCAM) stage_cams(d, cams_s);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t s = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
   // first record issued before the control word is needed
   ObsRec<SLIM> id0;
   id0.clear();
@@ -390,7 +392,9 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevProblem d, int sel) {
     cuv = d.obs_uv[s];
   }
   if (d.ctrl->done) return;
-  const int buf = d.ctrl->cur ^ sel;
+  // sel 1 inside the LM loop: the trial buffer recorded by k_pose_update; the stage
+  // API (ba_stage_scalars) asks for "the other buffer" of the host-set cur
+  const int buf = sel == 2 ? d.ctrl->tcur : (d.ctrl->cur ^ sel);
   const double *__restrict__ poses = d.poses[buf];
   const double *__restrict__ pts = d.pts[buf];
   // past-the-end prefetches are clamped to the last record: harmless gathers
@@ -441,7 +445,7 @@ __device__ long long g_ll_dbg[32];
 #define LL_STAMP()
 #endif
 template <bool LDSCAM>
-__global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
+__global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d, int sel) {
 #ifdef BA_LL_DBG
   __shared__ long long ll_s[32];
   const bool ll_on = blockIdx.x == 9000 && threadIdx.x == 0;
@@ -452,13 +456,14 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
   __shared__ double Cb[kBlock * 9];
   __shared__ double cams_s[kCamLds * 16];
   __shared__ int lq[kSchurLandmarks + 1];  // landmark observation offsets in the chunk
+  __shared__ double smc[4];
   // dependent-load chain: chunk record (+ control word) -> observation records
   // (+ this thread's landmark range) -> pose / point gathers
   const DevProblem::LmChunk lc = d.lm_chunk[blockIdx.x];
   const int done = d.ctrl->done;
-  const int buf = d.ctrl->cur;
+  const int buf = sel ? d.ctrl->tcur : d.ctrl->cur;
+  const int lb = sel ? d.ctrl->tlcur : d.ctrl->lcur;
   const double huber = d.ctrl->huber;
-  const double lp1 = 1.0 + d.ctrl->lambda;
   BA_KEEP_S((int)lc.pb);
   BA_KEEP_S((int)lc.ob);
   BA_KEEP_S(lc.l0);
@@ -483,6 +488,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
   LL_STAMP()
   const double *__restrict__ poses = d.poses[buf];
   const double *__restrict__ pts = d.pts[buf];
+  double *__restrict__ Wg = d.W[lb];
+  double cost_acc = 0.0;  // sum of ||r|| over this thread's observations (reference :381-433)
   // landmark observation ranges in LDS; running sums of thread (landmark, value)
   if (tid <= lc.nl) lq[tid] = (tid < lc.nl) ? (int)(q0 - ob) : lc.no;
   constexpr int kSumIt = (kSchurLandmarks * 9 + kBlock - 1) / kBlock;
@@ -504,6 +511,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
       const double *X = pts + (size_t)id.z * 3;
       ObsGeom g;
       project(cam, T, X[0], X[1], X[2], uv.x, uv.y, g);
+      cost_acc += sqrt(g.r0 * g.r0 + g.r1 * g.r1);
       double w, G[6], Rm[6];
       weight_and_G(cam, g, huber, w, G);
       make_R(G, T, Rm);
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
         // 0..2) and X_ij (ba_device.h kWStride)
         const int lp = (int)(id.w - pb);
         double *Wp = (lp < kSchurPairs) ? (Wst + lp * kWStride)
-                                        : (d.W + (size_t)id.w * kWStride);
+                                        : (Wg + (size_t)id.w * kWStride);
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
   {
     const int n2 = min(npair, kSchurPairs) * (kWStride / 2);
     const double2 *src = (const double2 *)Wst;
-    double2 *dst = (double2 *)(d.W + (size_t)pb * kWStride);
+    double2 *dst = (double2 *)(Wg + (size_t)pb * kWStride);
     constexpr int kIt = (kSchurPairs * (kWStride / 2) + kBlock - 1) / kBlock;
     double2 wv[kIt];
 #pragma unroll
@@ -595,23 +603,51 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
 #ifdef BA_LL_DBG
   if (ll_on) { for (int q = 0; q < 32; ++q) g_ll_dbg[q] = q < ll_n ? ll_s[q] : 0; }
 #endif
+  // cost partial of this workgroup (k_scalars adds them in block order)
+  {
+    const double tot = block_sum(cost_acc, smc);
+    if (tid == 0) d.lin_cost_part[blockIdx.x] = tot;
+  }
   if (!own) return;
-  // reference :846-856
-  double cd[6] = {c00 * lp1, c01, c02, c11 * lp1, c12, c22 * lp1};
-  double ci[6];
-  ldlt3_inverse(cd, ci);
-  double *Co = d.Cd + (size_t)i * 6;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) Co[k] = cd[k];
-  double *bo = d.b + (size_t)i * 3;
+  // undamped C_i (upper) and b_i; damping and the inverse follow the control step
+  // (k_damp_invert), because lambda is not known yet when the trial point is
+  // linearised
+  double *Co = d.Cu[lb] + (size_t)i * 6;
+  Co[0] = c00; Co[1] = c01; Co[2] = c02; Co[3] = c11; Co[4] = c12; Co[5] = c22;
+  double *bo = d.b[lb] + (size_t)i * 3;
   bo[0] = b0;
   bo[1] = b1;
   bo[2] = b2;
+}
+
+// Damping and landmark inverse (reference :846-856): Cinv_i = (C_i with its
+// diagonal times 1 + lambda)^-1 by the diagonally pivoted 3x3 LDL^T with
+// pseudo-inverse.  One thread per landmark; runs after the control
+// step has fixed lambda and the block buffer of the accepted point.
+__global__ __launch_bounds__(kBlock) void k_damp_invert(DevProblem d, int store_cd) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int ic = i < d.M ? i : 0;
+  const double lp1 = 1.0 + d.ctrl->lambda;
+  const int lb = d.ctrl->lcur;
+  const int done = d.ctrl->done;
+  const double *c = d.Cu[lb] + (size_t)ic * 6;
+  double cd[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cd[k] = c[k];
+  if (done || i >= d.M) return;
+  cd[0] *= lp1;
+  cd[3] *= lp1;
+  cd[5] *= lp1;
+  double ci[6];
+  ldlt3_inverse(cd, ci);
   double *Io = d.Cinv + (size_t)i * 6;
 #pragma unroll
   for (int k = 0; k < 6; ++k) Io[k] = ci[k];
-  // (Cinv_i b_i is formed where it is used, in k_backsub_update: 24 bytes per
-  //  landmark less to write here and to read there)
+  if (store_cd) {  // readers only (ba_get_C)
+    double *Do = d.Cd + (size_t)i * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Do[k] = cd[k];
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -651,7 +687,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d) {
   }
 
 template <bool LDSCAM>
-__global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
+__global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d, int sel) {
   // one WAVE per chunk (observations of ONE pose, see kPoseWaveTarget): no block-level
   // synchronisation in the loop, one 6-step shuffle reduction per accumulator
   // at the end
@@ -667,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   const int64_t b = d.achunk_begin[chc], e = d.achunk_end[chc];
   const int j = d.achunk_pose[chc];
   const int done = d.ctrl->done;
-  const int buf = d.ctrl->cur;
+  const int buf = sel ? d.ctrl->tcur : d.ctrl->cur;
   const double huber = d.ctrl->huber;
   BA_KEEP_S(__builtin_amdgcn_readfirstlane((int)b));
   BA_KEEP_S(__builtin_amdgcn_readfirstlane(j));
@@ -720,10 +756,12 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d) {
   }
 }
 
-// A_j (mirrored, damped) and a_j from the partial sums.
+// A_j (mirrored, UNDAMPED: the readers scale the diagonal by 1 + lambda, reference
+// :833-844) and a_j from the partial sums.
 // One thread per (pose, component): 21 upper + 6 gradient entries.
-__global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
+__global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d, int sel) {
   if (d.ctrl->done) return;
+  const int lb = sel ? d.ctrl->tlcur : d.ctrl->lcur;
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= d.N * 27) return;
   const int j = t / 27, e = t % 27;
@@ -738,12 +776,11 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d) {
       ++r;
     }
     const int c = r + k;
-    if (r == c) s *= (1.0 + d.ctrl->lambda);  // reference :833-844
-    d.A[(size_t)j * 36 + r * 6 + c] = s;
-    d.A[(size_t)j * 36 + c * 6 + r] = s;
+    d.A[lb][(size_t)j * 36 + r * 6 + c] = s;
+    d.A[lb][(size_t)j * 36 + c * 6 + r] = s;
   } else {
     const int r = e - 21;
-    d.a[(size_t)j * 6 + r] = -s;  // reference :809  a_j -= Q^T (w r)
+    d.a[lb][(size_t)j * 6 + r] = -s;  // reference :809  a_j -= Q^T (w r)
   }
 }
 
@@ -770,7 +807,7 @@ constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
 // issue the (contiguous, independent) global loads of one chunk into registers
 #define SCHUR_PREFETCH(cd_)                                                   \
   {                                                                           \
-    const double2 *src_ = (const double2 *)(d.W + (size_t)(cd_).p0 * kWStride); \
+    const double2 *src_ = (const double2 *)(Wg + (size_t)(cd_).p0 * kWStride);  \
     _Pragma("unroll") for (int k_ = 0; k_ < kSchurRW; ++k_) {                 \
       const int t_ = tid + k_ * kBlock;                                       \
       rw[k_] = (t_ < (cd_).np * 6) ? src_[t_] : make_double2(0.0, 0.0);       \
@@ -785,7 +822,7 @@ constexpr int kSchurRB = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
                               : make_uint4(0u, 0u, 0u, 0u);                   \
     _Pragma("unroll") for (int k_ = 0; k_ < kSchurRB; ++k_) {                 \
       const int t_ = tid + k_ * kBlock;                                       \
-      rb[k_] = (t_ < (cd_).nl * 3) ? d.b[(size_t)(cd_).l0 * 3 + t_] : 0.0;    \
+      rb[k_] = (t_ < (cd_).nl * 3) ? bg[(size_t)(cd_).l0 * 3 + t_] : 0.0;     \
     }                                                                         \
     /* raw value: any arithmetic here would wait for every load above */      \
     rpl = (tid < (cd_).np) ? d.pair_lm[(cd_).p0 + tid] : 0;                   \
@@ -826,9 +863,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   const uint32_t lane_word = d.sup_lane[(size_t)blockIdx.x * kBlock + tid];
   const int ns = sd.ns;
   const int done = d.ctrl->done;
+  const int lbs = d.ctrl->lcur;
   BA_KEEP_S(sd.chunk_begin);
   BA_KEEP_S(done);
   if (done) return;
+  const double *__restrict__ Wg = d.W[lbs];
+  const double *__restrict__ bg = d.b[lbs];
   // Lane table of the run (host: deal_lanes in ba_plan.cpp): every slot owns an
   // even number of lanes inside one wave, in proportion to its triple count.
   // A lane owns HALF a slot: rows 3h..3h+2 of the 6x6 block (18 accumulators +
@@ -1025,6 +1065,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
 // chunk of the block's global triple list, V computed on the fly.
 __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
   if (d.ctrl->done) return;
+  const double *__restrict__ Wg = d.W[d.ctrl->lcur];
+  const double *__restrict__ bg = d.b[d.ctrl->lcur];
   const int ch = blockIdx.x;
   double acc[36], racc[6];
 #pragma unroll
@@ -1036,9 +1078,9 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
     const int64_t p = d.tri_p[t];
     const bool dg = p == d.tri_q[t];
     double Wp[18];
-    expand_W(d.W + (size_t)p * kWStride, Wp);
+    expand_W(Wg + (size_t)p * kWStride, Wp);
     const double *ci = d.Cinv + (size_t)d.pair_lm[p] * 6;
-    const double *bi = d.b + (size_t)d.pair_lm[p] * 3;
+    const double *bi = bg + (size_t)d.pair_lm[p] * 3;
     const double b0 = dg ? bi[0] : 0.0, b1 = dg ? bi[1] : 0.0, b2 = dg ? bi[2] : 0.0;
     double v[18], w[18];
 #pragma unroll
@@ -1049,7 +1091,7 @@ __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
       v[r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
       racc[r] += v[r * 3 + 0] * b0 + v[r * 3 + 1] * b1 + v[r * 3 + 2] * b2;
     }
-    expand_W(d.W + (size_t)d.tri_q[t] * kWStride, w);
+    expand_W(Wg + (size_t)d.tri_q[t] * kWStride, w);
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -1089,8 +1131,12 @@ __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t bl
   double pre = 0.0;
   int pcj = 0, pck = 0;
   if (threadIdx.x < 42 && (e < 36 || j == k)) {
-    if (e >= 36) pre = d.a[(size_t)j * 6 + (e - 36)];
-    else if (j == k) pre = d.A[(size_t)j * 36 + e];
+    const int lb = d.ctrl->lcur;
+    if (e >= 36) pre = d.a[lb][(size_t)j * 6 + (e - 36)];
+    else if (j == k) {
+      pre = d.A[lb][(size_t)j * 36 + e];
+      if (e % 7 == 0) pre *= (1.0 + d.ctrl->lambda);  // damped diagonal, reference :833-844
+    }
     pcj = d.pose_col[j];
     pck = d.pose_col[k];
   }
@@ -1187,7 +1233,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
 // landmarks' own data} -> x_j gather; everything of one level is issued together.
 #define BACKSUB_ISSUE(t0_, np_)                                                 \
   {                                                                             \
-    const double2 *src_ = (const double2 *)(d.W + (size_t)(t0_) * kWStride);    \
+    const double2 *src_ = (const double2 *)(Wg + (size_t)(t0_) * kWStride);     \
     _Pragma("unroll") for (int k_ = 0; k_ < kBsRW; ++k_) {                      \
       const int t_ = tid + k_ * kBlock;                                         \
       rw[k_] = (t_ < (np_) * 6) ? src_[t_] : make_double2(0.0, 0.0);            \
@@ -1243,12 +1289,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
   if (tid < nk * 8) recs[tid] = ((const int *)d.lm_chunk)[(size_t)c0 * 8 + tid];
   const int done = d.ctrl->done;
   const int cur = d.ctrl->cur;
+  const int lbs = d.ctrl->lcur;
+  const double lp1 = 1.0 + d.ctrl->lambda;
   BA_KEEP_S((int)lc0.pb);
   BA_KEEP_S(lc0.np);
   BA_KEEP_S(done);
   if (done) return;
   const double *__restrict__ Xc = d.pts[cur];
   double *__restrict__ Xt = d.pts[cur ^ 1];
+  const double *__restrict__ Wg = d.W[lbs];
+  const double *__restrict__ bg = d.b[lbs];
+  const double *__restrict__ Cg = d.Cu[lbs];
   double2 rw[kBsRW];
   int rpj[kBsRX];
   // record of the chunk whose W is in the registers
@@ -1284,9 +1335,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
 #pragma unroll
       for (int e = 0; e < 3; ++e) Xi[e] = Xc[(size_t)i * 3 + e];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) bi[e] = d.b[(size_t)i * 3 + e];
+      for (int e = 0; e < 3; ++e) bi[e] = bg[(size_t)i * 3 + e];
 #pragma unroll
-      for (int e = 0; e < 6; ++e) C[e] = d.Cd[(size_t)i * 6 + e];
+      for (int e = 0; e < 6; ++e) C[e] = Cg[(size_t)i * 6 + e];
     }
     BS_STAMP()
     double bx0 = 0, bx1 = 0, bx2 = 0;  // sum_j W_ji^T x_j
@@ -1372,11 +1423,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
       Xo[0] = Xi[0] + y0;
       Xo[1] = Xi[1] + y1;
       Xo[2] = Xi[2] + y2;
-      // reference :443-452 with the damped C_i
+      // reference :443-452 with the damped C_i (diagonal times 1 + lambda, :846-852)
+      const double C0 = C[0] * lp1, C3 = C[3] * lp1, C5 = C[5] * lp1;
       double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;
-      const double r0 = y0 * C[0] + y1 * C[1] + y2 * C[2];
-      const double r1 = y0 * C[1] + y1 * C[3] + y2 * C[4];
-      const double r2 = y0 * C[2] + y1 * C[4] + y2 * C[5];
+      const double r0 = y0 * C0 + y1 * C[1] + y2 * C[2];
+      const double r1 = y0 * C[1] + y1 * C3 + y2 * C[4];
+      const double r2 = y0 * C[2] + y1 * C[4] + y2 * C5;
       e += r0 * y0 + r1 * y1 + r2 * y2;
       e += 2.0 * (y0 * bx0 + y1 * bx1 + y2 * bx2);
       est = e;
@@ -1410,6 +1462,12 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
   if (d.ctrl->done) return;
   __shared__ double sm[4];
   const int cur = d.ctrl->cur;
+  const int lbp = d.ctrl->lcur;
+  const double lp1p = 1.0 + d.ctrl->lambda;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // buffers of this iteration's trial point
+    d.ctrl->tcur = cur ^ 1;
+    d.ctrl->tlcur = lbp ^ 1;
+  }
   const double *__restrict__ Tc = d.poses[cur];
   double *__restrict__ Tt = d.poses[cur ^ 1];
   double est = 0.0, nrm = 0.0;
@@ -1462,8 +1520,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
       To[9 + r] = dR[r * 3 + 0] * T[9] + dR[r * 3 + 1] * T[10] +
                   dR[r * 3 + 2] * T[11] + dt[r];
     }
-    const double *aj = d.a + (size_t)j * 6;
-    const double *Aj = d.A + (size_t)j * 36;
+    const double *aj = d.a[lbp] + (size_t)j * 6;
+    const double *Aj = d.A[lbp] + (size_t)j * 36;
     double e = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) e += aj[r] * xj[r];
@@ -1472,7 +1530,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
     for (int c = 0; c < 6; ++c) {
       double rowc = 0.0;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) rowc += xj[r] * Aj[r * 6 + c];
+      for (int r = 0; r < 6; ++r)  // damped A_j (reference :833-844)
+        rowc += xj[r] * (r == c ? Aj[r * 6 + c] * lp1p : Aj[r * 6 + c]);
       q += rowc * xj[c];
     }
     est += e + q;
@@ -1493,16 +1552,32 @@ __device__ void control_step(const DevProblem &d);
 
 // mode 0: cost only; 1: all LM scalars; 2: all LM scalars, then the trust-region
 // control step by the same workgroup (single GPU: nothing to all-reduce in between)
+// cost_src 0: the k_cost partials (stage API: a cost pass over every observation);
+// 1: the partials of k_lin_landmarks (cost as a by-product of the linearisation)
+// plus, when fixed landmarks have observations, the k_cost partials of those
 constexpr int kScalBlock = 1024;
-__global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode) {
+__global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode, int cost_src) {
   if (d.ctrl->done) return;
   double c = 0.0, e = 0.0, n = 0.0, pe = 0.0, pn = 0.0;
-  {  // both rounds of the cost partials requested at once
+  if (cost_src == 0 || d.n_obs_lm < d.n_obs) {  // both rounds of the cost partials requested at once
     static_assert(kCostGrid <= 2 * kScalBlock, "two loads per thread");
     const int k1 = threadIdx.x + kScalBlock;
     const double c0 = d.cost_part[threadIdx.x < kCostGrid ? threadIdx.x : 0];
     const double c1 = d.cost_part[k1 < kCostGrid ? k1 : 0];
     c = (threadIdx.x < kCostGrid ? c0 : 0.0) + (k1 < kCostGrid ? c1 : 0.0);
+  }
+  if (cost_src == 1) {  // eight independent loads in flight per thread
+    const double *lp = d.lin_cost_part;
+    for (int k0 = threadIdx.x; k0 < d.n_bchunk; k0 += 8 * kScalBlock) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * kScalBlock;
+        v[u] = k < d.n_bchunk ? lp[k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c += v[u];
+    }
   }
   if (mode >= 1) {
     const double2 *lp = (const double2 *)d.lm_part;
@@ -1589,10 +1664,12 @@ __device__ void control_step(const DevProblem &d) {
     status = 0;
     rho = 0.0;
     c->cur ^= 1;
+    c->lcur ^= 1;
   } else {
     if (rho > 0.25) {
       status = 0;
-      c->cur ^= 1;  // the trial buffer becomes the accepted one
+      c->cur ^= 1;   // the trial buffer becomes the accepted one ...
+      c->lcur ^= 1;  // ... and so does the linearisation made at the trial point
     } else {
       status = 2;   // keep the reserved parameters (reference :943)
     }
@@ -1648,36 +1725,47 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
-void launch_cost(const DevProblem &d, int sel, hipStream_t s) {
+void launch_cost(const DevProblem &d, int sel, int64_t begin, hipStream_t s) {
+  if (begin >= d.n_obs) return;
   const bool lds = d.n_cam <= kCamLds, slim = d.obs_cp != nullptr;
   if (lds && slim) {
-    BA_LAUNCH(K_COST, (k_cost<true, true>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+    BA_LAUNCH(K_COST, (k_cost<true, true>), dim3(kCostGrid), dim3(kBlock), s, d, sel, begin);
   } else if (lds) {
-    BA_LAUNCH(K_COST, (k_cost<true, false>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+    BA_LAUNCH(K_COST, (k_cost<true, false>), dim3(kCostGrid), dim3(kBlock), s, d, sel, begin);
   } else if (slim) {
-    BA_LAUNCH(K_COST, (k_cost<false, true>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+    BA_LAUNCH(K_COST, (k_cost<false, true>), dim3(kCostGrid), dim3(kBlock), s, d, sel, begin);
   } else {
-    BA_LAUNCH(K_COST, (k_cost<false, false>), dim3(kCostGrid), dim3(kBlock), s, d, sel);
+    BA_LAUNCH(K_COST, (k_cost<false, false>), dim3(kCostGrid), dim3(kBlock), s, d, sel, begin);
   }
 }
 
-void launch_linearize(const DevProblem &d, hipStream_t s) {
-  if (d.n_bchunk > 0)
-  {
+void launch_lin_landmarks(const DevProblem &d, int sel, hipStream_t s) {
+  if (d.n_bchunk <= 0) return;
+  if (d.n_cam <= kCamLds)
+    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<true>, dim3(d.n_bchunk), dim3(kBlock), s, d, sel);
+  else
+    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<false>, dim3(d.n_bchunk), dim3(kBlock), s, d, sel);
+}
+
+void launch_lin_poses(const DevProblem &d, int sel, hipStream_t s) {
+  if (d.n_achunk > 0) {
     if (d.n_cam <= kCamLds)
-      BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<true>, dim3(d.n_bchunk), dim3(kBlock), s, d);
+      BA_LAUNCH(K_LIN_POSES, k_lin_poses<true>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d, sel);
     else
-      BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<false>, dim3(d.n_bchunk), dim3(kBlock), s, d);
-  }
-  if (d.n_achunk > 0)
-  {
-    if (d.n_cam <= kCamLds)
-      BA_LAUNCH(K_LIN_POSES, k_lin_poses<true>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d);
-    else
-      BA_LAUNCH(K_LIN_POSES, k_lin_poses<false>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d);
+      BA_LAUNCH(K_LIN_POSES, k_lin_poses<false>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), s, d, sel);
   }
   if (d.N > 0)
-    BA_LAUNCH(K_POSE_FINALIZE, k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), s, d);
+    BA_LAUNCH(K_POSE_FINALIZE, k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), s, d, sel);
+}
+
+void launch_damp_invert(const DevProblem &d, hipStream_t s) {
+  if (d.M > 0)
+    BA_LAUNCH(K_DAMP_INVERT, k_damp_invert, dim3(cdiv(d.M, kBlock)), dim3(kBlock), s, d, 0);
+}
+// reader variant: also stores the damped C_i (ba_get_C)
+void launch_damp_invert_export(const DevProblem &d, hipStream_t s) {
+  if (d.M > 0)
+    hipLaunchKernelGGL(k_damp_invert, dim3(cdiv(d.M, kBlock)), dim3(kBlock), 0, s, d, 1);
 }
 
 #ifdef BA_LL_DBG
@@ -1690,66 +1778,26 @@ extern "C" int ba_debug_read(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_dbg), sizeof(long long) * 4 * 160);
 }
 #endif
-void launch_schur(const DevProblem &d, hipStream_t s) {
-  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, s);
+void launch_schur_accumulate(const DevProblem &d, hipStream_t s) {
   if (d.n_sup > 0)
     BA_LAUNCH(K_SCHUR_LDS, k_schur_lds, dim3(d.n_sup), dim3(kBlock), s, d);
   if (d.n_tchunk > 0)
     BA_LAUNCH(K_SCHUR_PARTIAL, k_schur_partial, dim3(d.n_tchunk), dim3(64), s, d);
-  if (d.B > 0)
-    BA_LAUNCH(K_SCHUR_FINAL, k_schur_final, dim3((unsigned)d.B), dim3(kBlock), s,
-                       d);
 }
 
-// linearisation + Schur complement with the pose side on a second stream: the
-// pose-side sums (A_j, a_j) and the reset of the factor tiles depend only on
-// the current parameters and are first needed by k_schur_final,
-// so they run beside k_lin_landmarks and k_schur_lds instead of after them.
-void launch_linearize_schur_overlapped(const DevProblem &d, hipStream_t s,
-                                       hipStream_t s2, hipEvent_t fork,
-                                       hipEvent_t join, bool direct) {
-  (void)hipEventRecord(fork, s);
-  (void)hipStreamWaitEvent(s2, fork, 0);
-  launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, s2);
-  if (d.n_achunk > 0) {
-    if (d.n_cam <= kCamLds)
-      hipLaunchKernelGGL(k_lin_poses<true>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), 0, s2, d);
-    else
-      hipLaunchKernelGGL(k_lin_poses<false>, dim3(cdiv(d.n_achunk, kBlock / 64)), dim3(kBlock), 0, s2, d);
-  }
-  if (d.N > 0)
-    hipLaunchKernelGGL(k_pose_finalize, dim3(cdiv((int64_t)d.N * 27, kBlock)), dim3(kBlock), 0, s2, d);
-  (void)hipEventRecord(join, s2);
-  if (d.n_bchunk > 0)
-  {
-    if (d.n_cam <= kCamLds)
-      hipLaunchKernelGGL(k_lin_landmarks<true>, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
-    else
-      hipLaunchKernelGGL(k_lin_landmarks<false>, dim3(d.n_bchunk), dim3(kBlock), 0, s, d);
-  }
-  if (d.n_sup > 0) hipLaunchKernelGGL(k_schur_lds, dim3(d.n_sup), dim3(kBlock), 0, s, d);
-  if (d.n_tchunk > 0)
-    hipLaunchKernelGGL(k_schur_partial, dim3(d.n_tchunk), dim3(64), 0, s, d);
-  (void)hipStreamWaitEvent(s, join, 0);
-  if (d.B > 0) {
-    if (direct)
-      hipLaunchKernelGGL(k_schur_final_direct, dim3((unsigned)d.B), dim3(kBlock), 0, s, d);
-    else
-      hipLaunchKernelGGL(k_schur_final, dim3((unsigned)d.B), dim3(kBlock), 0, s, d);
-  }
+void launch_schur_final(const DevProblem &d, bool direct, hipStream_t s) {
+  if (d.B <= 0) return;
+  if (direct)
+    BA_LAUNCH(K_SCHUR_FINAL, k_schur_final_direct, dim3((unsigned)d.B), dim3(kBlock), s, d);
+  else
+    BA_LAUNCH(K_SCHUR_FINAL, k_schur_final, dim3((unsigned)d.B), dim3(kBlock), s, d);
 }
 
-// back-substitution with the pose update (needs x only) on the second stream
-void launch_backsub_update_overlapped(const DevProblem &d, hipStream_t s,
-                                      hipStream_t s2, hipEvent_t fork,
-                                      hipEvent_t join) {
-  (void)hipEventRecord(fork, s);
-  (void)hipStreamWaitEvent(s2, fork, 0);
-  hipLaunchKernelGGL(k_pose_update, dim3(kPoseGrid), dim3(kBlock), 0, s2, d);
-  (void)hipEventRecord(join, s2);
-  if (d.n_bchunk > 0)
-    hipLaunchKernelGGL(k_backsub_update, dim3(cdiv(d.n_bchunk, kBsChunks)), dim3(kBlock), 0, s, d);
-  (void)hipStreamWaitEvent(s, join, 0);
+void launch_schur(const DevProblem &d, bool direct, bool with_init, hipStream_t s) {
+  if (with_init)
+    launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, s);
+  launch_schur_accumulate(d, s);
+  launch_schur_final(d, direct, s);
 }
 
 void launch_scatter(const DevProblem &d, hipStream_t s) {
@@ -1764,12 +1812,12 @@ void launch_backsub_update(const DevProblem &d, hipStream_t s) {
   BA_LAUNCH(K_POSE_UPDATE, k_pose_update, dim3(kPoseGrid), dim3(kBlock), s, d);
 }
 
-void launch_scalars(const DevProblem &d, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 1);
+void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s) {
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 1, cost_src);
 }
 
-void launch_scalars_and_control(const DevProblem &d, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 2);
+void launch_scalars_and_control(const DevProblem &d, int cost_src, hipStream_t s) {
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 2, cost_src);
 }
 
 void launch_control(const DevProblem &d, hipStream_t s) {
@@ -1780,9 +1828,9 @@ void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s) {
   BA_LAUNCH(K_CONTROL, k_init_ctrl_cost, dim3(1), dim3(64), s, d);
 }
 
-// exposed for ba_api: initial-cost scalar reduction (mode 0)
-void launch_scalars_cost_only(const DevProblem &d, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 0);
+// initial-cost scalar reduction (mode 0)
+void launch_scalars_cost_only(const DevProblem &d, int cost_src, hipStream_t s) {
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 0, cost_src);
 }
 
 }  // namespace ba
