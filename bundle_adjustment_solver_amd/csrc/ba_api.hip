@@ -201,15 +201,24 @@ int enqueue_iteration(ba_handle *h) {
   mark(h, 4);
   if (ov) {
     // pose side of the trial-point linearisation and the reset of the factor
-    // tiles: first needed by the NEXT iteration's k_schur_final
+    // tiles: first needed by the NEXT iteration's k_schur_final.  BA_POSE_LATE=1
+    // (default) starts them after k_lin_landmarks, beside the control step, the
+    // damping kernel and the first part of k_schur_lds; 0 beside k_lin_landmarks.
+    static const bool late = !(getenv("BA_POSE_LATE") && getenv("BA_POSE_LATE")[0] == '0');
+    if (late) {
+      ba::launch_lin_landmarks(d, 1, s);
+      if (d.n_obs_lm < d.n_obs) ba::launch_cost(d, 2, d.n_obs_lm, s);
+    }
     (void)hipEventRecord(h->ev_fork, s);
     (void)hipStreamWaitEvent(h->side_stream, h->ev_fork, 0);
     ba::launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, h->side_stream);
     ba::launch_lin_poses(d, 1, h->side_stream);
     (void)hipEventRecord(h->ev_join, h->side_stream);
     h->side_pending = true;
-    ba::launch_lin_landmarks(d, 1, s);
-    if (d.n_obs_lm < d.n_obs) ba::launch_cost(d, 2, d.n_obs_lm, s);
+    if (!late) {
+      ba::launch_lin_landmarks(d, 1, s);
+      if (d.n_obs_lm < d.n_obs) ba::launch_cost(d, 2, d.n_obs_lm, s);
+    }
   } else {
     enqueue_linearize(h, 1);
   }

@@ -799,6 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d, int sel)
 // LDS, so HBM latency is hidden.  One reduction over the tps lanes and one
 // 288-byte store per slot at the very end; slots of one block are summed
 // across super-runs by k_schur_final in run order: deterministic, no atomics.
+constexpr int kWLds = 14;  // LDS stride of a compact W record in k_schur_lds (see there)
 constexpr int kSchurRW = (kSchurPairs * (kWStride / 2) + kBlock - 1) / kBlock;
 constexpr int kSchurRC = (kSchurLandmarks * 3 + kBlock - 1) / kBlock;
 static_assert(kSchurTri <= 4 * kBlock, "one uint4 of triple words per lane");
@@ -850,7 +851,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   int dbg_n = 0;
   DBG_STAMP()
 #endif
-  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * kWStride];  // compact {K, X_ij} records
+  // compact {K, X_ij} records at a stride of 14 doubles: the triple loop reads them with
+  // 16-byte loads at arbitrary pair indices, and 112 bytes (28 banks, gcd with 64 = 4) spread
+  // over all LDS banks where the packed 96 bytes (24 banks, gcd 8) reach only half of them
+  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * kWLds];
   __shared__ __attribute__((aligned(16))) double Vs[kSchurPairs * 18];
   __shared__ __attribute__((aligned(16))) double Cs[kSchurLandmarks * 6];
   __shared__ double Bs[kSchurLandmarks * 3];
@@ -903,7 +907,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
 #pragma unroll
       for (int k = 0; k < kSchurRW; ++k) {
         const int t = tid + k * kBlock;
-        if (t < cd.np * 6) dst[t] = rw[k];
+        const int pr = t / 6;
+        if (t < cd.np * 6) dst[pr * (kWLds / 2) + (t - pr * 6)] = rw[k];
       }
       double2 *cdst = (double2 *)Cs;
 #pragma unroll
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
       const int pr = tid & (kSchurPairs - 1);
       const bool hi = tid >= kSchurPairs;  // wave-uniform
       if (pr < np) {
-        const double *kk = Ws + pr * kWStride;
+        const double *kk = Ws + pr * kWLds;
         const double *ci = Cs + (int)Pl[pr] * 6;
         double k9[9], c6[6], x3[3], wr[9];
 #pragma unroll
@@ -996,7 +1001,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
         //   sum_m v_m W[c][m]      = t_c           (c < 3),  t = K v
         //   sum_m v_m W[3 + a][m]  = (X x t)_a
         // 12 instead of 18 LDS doubles per triple; the loop is LDS-bandwidth bound
-        const double2 *wp = (const double2 *)(Ws + qq * kWStride);
+        const double2 *wp = (const double2 *)(Ws + qq * kWLds);
         // diagonal triple (p == q): also B Cinv b of this pair (reference :864);
         // b is read unconditionally and masked (no divergent LDS reads)
         const double *bp = Bs + ((pq >> 8) & 0xffu) * 3;
