@@ -535,6 +535,17 @@ int ba_finalize(ba_handle *h) {
                         pl.chunk_desc.size() * sizeof(ba::Plan::ChunkDesc), hipMemcpyHostToDevice));
   }
   if (h->dalloc(&d.spart2, (size_t)d.n_slot * ba::kSlotStride)) return -1;
+  {
+    static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 64,
+                  "group descriptor layout");
+    d.n_grp32 = (int)pl.grp32.size();
+    d.n_grp64 = (int)pl.grp64.size();
+    if (h->dalloc(&d.grp32, pl.grp32.size()) || h->dalloc(&d.grp64, pl.grp64.size())) return -1;
+    if (d.n_grp32)
+      HIP_TRY(hipMemcpy(d.grp32, pl.grp32.data(), pl.grp32.size() * sizeof(ba::Plan::GrpDesc), hipMemcpyHostToDevice));
+    if (d.n_grp64)
+      HIP_TRY(hipMemcpy(d.grp64, pl.grp64.data(), pl.grp64.size() * sizeof(ba::Plan::GrpDesc), hipMemcpyHostToDevice));
+  }
 
   // per-iteration storage
   for (int k = 0; k < 2; ++k) {
@@ -1089,7 +1100,7 @@ const char *ba_kernel_name(int id) {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
       "k_schur_lds", "k_schur_partial", "k_schur_final", "k_scatter",
       "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_chol_diag_trsm", "k_chol_tail", "k_backsub_update",
-      "k_pose_update", "k_scalars", "k_control", "k_damp_invert"};
+      "k_pose_update", "k_scalars", "k_control", "k_damp_invert", "k_schur_grp"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
 }
 

@@ -93,6 +93,14 @@ struct DevProblem {
     int64_t p0, tb, sp;
     int32_t l0, nl, np, nt;
   };
+  // covisibility groups (k_schur_grp): layout-identical to Plan::GrpDesc
+  struct GrpDesc {
+    int64_t p0;
+    int32_t l0, nl, d, s0;
+    int32_t pose[10];
+  };
+  GrpDesc *grp32, *grp64;  // pose sets of <= 5 / 6..10 poses
+  int n_grp32, n_grp64;
   SupDesc *sup_desc;
   uint32_t *sup_lane;  // n_sup*256: lane -> (slot, half, position, lanes per half) of k_schur_lds
   ChunkDesc *chunk_desc;
@@ -167,7 +175,7 @@ enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
   K_SCHUR_LDS, K_SCHUR_PARTIAL, K_SCHUR_FINAL, K_SCATTER,
   K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_CHOL_DIAG_TRSM, K_CHOL_TAIL, K_BACKSUB_UPDATE,
-  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_DAMP_INVERT, K_COUNT
+  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_DAMP_INVERT, K_SCHUR_GRP, K_COUNT
 };
 struct KernelTimer {
   bool on = false;

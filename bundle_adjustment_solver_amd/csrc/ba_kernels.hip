@@ -58,6 +58,7 @@ void KernelTimer::reset() {
 namespace {
 
 constexpr int kBlock = 256;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // Wave-wide sum on the DPP network (no LDS round trips): xor-1, xor-2,
 // half-mirror and mirror steps leave every lane with the total of its row of
@@ -1066,6 +1067,220 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
   }
 }
 
+// --------------------------------------------------------------------------
+// Covisibility groups (host: ba_plan.cpp): n landmarks seen by the IDENTICAL set
+// of d optimisable poses.  Their part of the Schur complement (reference
+// :859-872) is, for every pose pair (jj, kk) of the set,
+//     sum_i V_(jj)i W_(kk)i^T ,   V = W Cinv,
+// i.e. ONE dense product  [V]^T [W]  with  [V], [W] : (3 n) x (6 d)  (row 3 i + m
+// = landmark i, coordinate m; column 6 jj + r = pose jj, row r of its 6x3 block),
+// and the right-hand side part sum_i V_ji b_i is one more column (b) of [W].
+// The product runs on v_mfma_f64_16x16x4_f64: the super-run kernel's triple loop
+// is bound by LDS bandwidth (24 doubles per 63 FMAs and lane); here an LDS double
+// feeds 16 FMAs.
+// One workgroup per group (or piece of a large group); its four waves work
+// INDEPENDENTLY on every fourth chunk of floor(64 / d) landmarks (one lane per
+// (landmark, pose) pair): the lane turns its compact W record and Cinv_i into its
+// 6x3 blocks of [V] and [W] in the wave's private LDS image, then the wave
+// multiplies the image into its NT (NT + 1) / 2 upper 16x16 accumulator tiles.  No
+// workgroup barrier inside the loop (a wave's LDS operations are ordered), so the
+// VALU / LDS-store phase of one wave overlaps the MFMA phase of the others; the
+// operands of the next two chunks are in flight meanwhile (register ring).  The
+// four partial tiles are added in wave order at the very end (deterministic) and
+// leave as d (d + 1) / 2 slot partials that k_schur_final sums with the super-run
+// slots.
+// LDS image: entry (k, col) at ((k >> 1) * TW + col) * 2 + (k & 1): the four k rows
+// of one MFMA operand read (lanes: col = lane & 15, k = 4 ks + (lane >> 4)) are two
+// 256-byte rows of 16-byte (k even, k odd) cells — two conflict-free passes, no padding.
+#ifndef BA_GRP_KRW
+#define BA_GRP_KRW 36
+#endif
+#ifdef BA_GRP_DBG
+__device__ long long g_grp_dbg[256];
+#define GRP_STAMP() { if (gdbg_on && gdbg_n < 256) gdbg_s[gdbg_n++] = clock64(); }
+#else
+#define GRP_STAMP()
+#endif
+template <int NT>
+__global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void k_schur_grp(DevProblem d, const DevProblem::GrpDesc *grps) {
+  constexpr int TW = 16 * NT;             // padded width: 6 d (+ 1 for b) <= TW
+#ifndef BA_GRP_KRW
+#define BA_GRP_KRW 36
+#endif
+  constexpr int KRW = NT == 2 ? BA_GRP_KRW : 20;  // k rows of a wave's image (multiple of 4)
+  constexpr int NTILE = NT * (NT + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double VA[4][KRW * TW];
+  __shared__ __attribute__((aligned(16))) double WB[4][KRW * TW];
+#ifdef BA_GRP_DBG
+  __shared__ long long gdbg_s[256];
+  const bool gdbg_on = blockIdx.x == 600 && threadIdx.x == 0;
+  int gdbg_n = 0;
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const DevProblem::GrpDesc gd = grps[blockIdx.x];
+  const int done = d.ctrl->done;
+  const int lb = d.ctrl->lcur;
+  BA_KEEP_S(gd.l0);
+  BA_KEEP_S(done);
+  if (done) return;
+  const double *__restrict__ Wg = d.W[lb];
+  const double *__restrict__ bg = d.b[lb];
+  const int dd = gd.d;
+  const int nlw = min(64 / dd, KRW / 3);       // landmarks per wave chunk
+  const int il = lane / dd, jj = lane - il * dd;  // this lane's pair inside a chunk
+  const int nch = (gd.nl + nlw - 1) / nlw;
+  double *va = VA[wv], *wb = WB[wv];
+  for (int e = lane; e < KRW * TW; e += 64) {  // rows a full chunk never writes stay zero
+    va[e] = 0.0;
+    wb[e] = 0.0;
+  }
+  // operands of a chunk, requested two chunks ahead (register ring; the loop is
+  // unrolled by two so that the ring index is static)
+  double2 rw[2][6], rc[2][3];
+  double rb[2][3];
+#define GRP_PREFETCH(B, ch_)                                                        \
+  {                                                                                 \
+    const int c0_ = (ch_) * nlw;                                                    \
+    const bool on_ = il < min(nlw, gd.nl - c0_);                                    \
+    const double2 *wp_ = (const double2 *)(Wg + (size_t)(gd.p0 + (int64_t)c0_ * dd + (on_ ? lane : 0)) * kWStride); \
+    const int lm_ = gd.l0 + c0_ + (on_ ? il : 0);                                   \
+    const double2 *cp_ = (const double2 *)(d.Cinv + (size_t)lm_ * 6);               \
+    _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) rw[B][k_] = wp_[k_];           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) rc[B][k_] = cp_[k_];           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) rb[B][k_] = bg[(size_t)lm_ * 3 + k_]; \
+  }
+  v4f64 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (wv < nch) GRP_PREFETCH(0, wv)
+  if (wv + 4 < nch) GRP_PREFETCH(1, wv + 4)
+#define GRP_IDX(k_, col_) ((((k_) >> 1) * TW + (col_)) * 2 + ((k_) & 1))
+#define GRP_STAGE(B)                                                                \
+  if (ch < nch) {                                                                   \
+    GRP_STAMP()                                                                     \
+    const int nlc = min(nlw, gd.nl - ch * nlw);                                     \
+    if (il < nlc) {                                                                 \
+      /* W_p (6x3) from its compact record, V_p = W_p Cinv_i */                     \
+      const double k9[9] = {rw[B][0].x, rw[B][0].y, rw[B][1].x, rw[B][1].y, rw[B][2].x, \
+                            rw[B][2].y, rw[B][3].x, rw[B][3].y, rw[B][4].x};        \
+      const double x0 = rw[B][4].y, x1 = rw[B][5].x, x2 = rw[B][5].y;               \
+      const double c6[6] = {rc[B][0].x, rc[B][0].y, rc[B][1].x, rc[B][1].y, rc[B][2].x, rc[B][2].y}; \
+      double w[18];                                                                 \
+      _Pragma("unroll") for (int e = 0; e < 9; ++e) w[e] = k9[e];                   \
+      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
+        w[9 + c] = x1 * k9[6 + c] - x2 * k9[3 + c];                                 \
+        w[12 + c] = x2 * k9[c] - x0 * k9[6 + c];                                    \
+        w[15 + c] = x0 * k9[3 + c] - x1 * k9[c];                                    \
+      }                                                                             \
+      const int kb = 3 * il, cb = 6 * jj;                                           \
+      const int i0 = GRP_IDX(kb, cb), i1 = GRP_IDX(kb + 1, cb), i2 = GRP_IDX(kb + 2, cb); \
+      _Pragma("unroll") for (int r = 0; r < 6; ++r) {                               \
+        const double w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];           \
+        va[i0 + 2 * r] = w0 * c6[0] + w1 * c6[1] + w2 * c6[2];                      \
+        va[i1 + 2 * r] = w0 * c6[1] + w1 * c6[3] + w2 * c6[4];                      \
+        va[i2 + 2 * r] = w0 * c6[2] + w1 * c6[4] + w2 * c6[5];                      \
+        wb[i0 + 2 * r] = w0;                                                        \
+        wb[i1 + 2 * r] = w1;                                                        \
+        wb[i2 + 2 * r] = w2;                                                        \
+      }                                                                             \
+      if (jj == 0) { /* the b column of [W]: column 6 d */                          \
+        wb[GRP_IDX(kb, 6 * dd)] = rb[B][0];                                         \
+        wb[GRP_IDX(kb + 1, 6 * dd)] = rb[B][1];                                     \
+        wb[GRP_IDX(kb + 2, 6 * dd)] = rb[B][2];                                     \
+      }                                                                             \
+    }                                                                               \
+    const int nks = (3 * nlc + 3) >> 2;                                             \
+    if (nlc < nlw) { /* partial last chunk: stale rows up to the next multiple of four */ \
+      for (int e = lane; e < (4 * nks - 3 * nlc) * TW; e += 64) {                   \
+        const int k_ = 3 * nlc + e / TW, c_ = e - (e / TW) * TW;                    \
+        va[GRP_IDX(k_, c_)] = 0.0;                                                  \
+        wb[GRP_IDX(k_, c_)] = 0.0;                                                  \
+      }                                                                             \
+    }                                                                               \
+    GRP_STAMP()                                                                     \
+    if (ch + 8 < nch) GRP_PREFETCH(B, ch + 8)                                       \
+    GRP_STAMP()                                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                          \
+    __builtin_amdgcn_wave_barrier();                                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
+    {                                                                               \
+      /* operands of k step ks: rows 4 ks + lk -> cell row 2 ks + (lk >> 1), half lk & 1 */ \
+      const double *ap = va + ((lk >> 1) * TW + lr) * 2 + (lk & 1);                 \
+      const double *bp = wb + ((lk >> 1) * TW + lr) * 2 + (lk & 1);                 \
+      double a[NT], b[NT], an[NT], bn[NT];                                          \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                              \
+        a[t] = ap[32 * t];                                                          \
+        b[t] = bp[32 * t];                                                          \
+      }                                                                             \
+      for (int ks = 0; ks < nks; ++ks) {                                            \
+        const int kn = ks + 1 < nks ? ks + 1 : ks; /* operands of the next step first */ \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                            \
+          an[t] = ap[kn * 4 * TW + 32 * t];                                         \
+          bn[t] = bp[kn * 4 * TW + 32 * t];                                         \
+        }                                                                           \
+        int tile = 0;                                                               \
+        _Pragma("unroll") for (int ti = 0; ti < NT; ++ti)                           \
+        _Pragma("unroll") for (int tj = ti; tj < NT; ++tj) {                        \
+          acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[tile], 0, 0, 0); \
+          ++tile;                                                                   \
+        }                                                                           \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                            \
+          a[t] = an[t];                                                             \
+          b[t] = bn[t];                                                             \
+        }                                                                           \
+      }                                                                             \
+    }                                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                          \
+    __builtin_amdgcn_wave_barrier();                                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
+    GRP_STAMP()                                                                     \
+    ch += 4;                                                                        \
+  }
+  for (int ch = wv; ch < nch;) {
+    GRP_STAGE(0)
+    GRP_STAGE(1)
+  }
+#undef GRP_STAGE
+#undef GRP_IDX
+#undef GRP_PREFETCH
+  GRP_STAMP()
+#ifdef BA_GRP_DBG
+  if (gdbg_on) for (int q = 0; q < 256; ++q) g_grp_dbg[q] = q < gdbg_n ? gdbg_s[q] : 0;
+#endif
+  // add the four waves' partial tiles in wave order, one tile at a time, and
+  // scatter the block entries to the group's slots
+  __syncthreads();
+  double *R = &VA[0][0];  // 4 x 256 doubles
+  int tile = 0;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < NT; ++tj) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) R[wv * 256 + g * 64 + lane] = acc[tile][g];
+      __syncthreads();
+      {
+        const double v = ((R[tid] + R[256 + tid]) + R[512 + tid]) + R[768 + tid];
+        const int g = tid >> 6, ln = tid & 63;
+        const int row = 16 * ti + (ln >> 4) + 4 * g;  // V side: 6 pj + r
+        const int col = 16 * tj + (ln & 15);          // W side: 6 pk + c, or the b column
+        const int pj = row / 6, r = row - 6 * pj;
+        if (pj < dd) {
+          const int sj = gd.s0 + pj * dd - (pj * (pj - 1)) / 2;  // slot of (pj, pj)
+          if (col == 6 * dd) {
+            d.spart2[(size_t)sj * kSlotStride + 36 + r] = v;
+          } else if (col < 6 * dd) {
+            const int pk = col / 6, c = col - 6 * pk;
+            if (pk >= pj) d.spart2[(size_t)(sj + (pk - pj)) * kSlotStride + r * 6 + c] = v;
+          }
+        }
+      }
+      __syncthreads();
+      ++tile;
+    }
+}
+
 // Same sums for landmarks seen by more than kSchurPairs poses: one wave per
 // chunk of the block's global triple list, V computed on the fly.
 __global__ __launch_bounds__(64) void k_schur_partial(DevProblem d) {
@@ -1778,12 +1993,21 @@ extern "C" int ba_debug_read_ll(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ll_dbg), sizeof(long long) * 32);
 }
 #endif
+#ifdef BA_GRP_DBG
+extern "C" int ba_debug_read_grp(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grp_dbg), sizeof(long long) * 256);
+}
+#endif
 #ifdef BA_SCHUR_DBG
 extern "C" int ba_debug_read(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_dbg), sizeof(long long) * 4 * 160);
 }
 #endif
 void launch_schur_accumulate(const DevProblem &d, hipStream_t s) {
+  if (d.n_grp32 > 0)
+    BA_LAUNCH(K_SCHUR_GRP, k_schur_grp<2>, dim3(d.n_grp32), dim3(kBlock), s, d, d.grp32);
+  if (d.n_grp64 > 0)
+    BA_LAUNCH(K_SCHUR_GRP, k_schur_grp<4>, dim3(d.n_grp64), dim3(kBlock), s, d, d.grp64);
   if (d.n_sup > 0)
     BA_LAUNCH(K_SCHUR_LDS, k_schur_lds, dim3(d.n_sup), dim3(kBlock), s, d);
   if (d.n_tchunk > 0)

@@ -217,15 +217,82 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     }
   }
   pl.M = (int)pl.pt_user_of_int.size();
+  // ---- covisibility groups: landmarks with the identical set of optimisable
+  // poses (1..kGrpMaxPoses of them) in groups of >= kGrpMinLandmarks come FIRST,
+  // group after group (groups ordered by their pose lists, i.e. still by first
+  // observing pose; landmarks of a group in locality order); k_schur_grp turns
+  // each group into one dense product.  Everything else keeps the locality order
+  // and goes through the super-runs. ----
+  pl.M_grp = 0;
+  pl.grp_range.clear();
+  if (pl.M > 0 && !(getenv("BA_NO_GROUPS") && getenv("BA_NO_GROUPS")[0] == '1')) {
+    const int M0 = pl.M;
+    std::vector<uint64_t> keys;
+    keys.reserve(in.n_obs / in.world + 16);
+    for (int64_t k = 0; k < in.n_obs; ++k) {
+      const int32_t pi = pl.pt_int_of_user[in.obs_pt[k]];
+      const int32_t ji = pl.pose_int_of_user[in.obs_pose[k]];
+      if (pi >= 0 && ji < N) keys.push_back(((uint64_t)(uint32_t)pi << 32) | (uint32_t)ji);
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<int64_t> kp(M0 + 1, 0);
+    for (uint64_t key : keys) kp[(key >> 32) + 1]++;
+    for (int i = 0; i < M0; ++i) kp[i + 1] += kp[i];
+    auto deg = [&](int i) { return (int)(kp[i + 1] - kp[i]); };
+    auto less_sig = [&](int a, int b) {  // lexicographic on the pose lists, shorter first on ties
+      const int da = deg(a), db = deg(b);
+      for (int t = 0; t < std::min(da, db); ++t) {
+        const uint32_t pa = (uint32_t)keys[kp[a] + t], pb = (uint32_t)keys[kp[b] + t];
+        if (pa != pb) return pa < pb;
+      }
+      return da < db;
+    };
+    auto same_sig = [&](int a, int b) {
+      if (deg(a) != deg(b)) return false;
+      for (int t = 0; t < deg(a); ++t)
+        if ((uint32_t)keys[kp[a] + t] != (uint32_t)keys[kp[b] + t]) return false;
+      return true;
+    };
+    std::vector<int32_t> cand;
+    for (int i = 0; i < M0; ++i)
+      if (deg(i) >= 1 && deg(i) <= kGrpMaxPoses) cand.push_back(i);
+    std::stable_sort(cand.begin(), cand.end(), less_sig);  // stable: locality order inside a group
+    std::vector<uint8_t> grouped(M0, 0);
+    std::vector<int32_t> neworder;
+    neworder.reserve(M0);
+    size_t a = 0;
+    while (a < cand.size()) {
+      size_t b = a + 1;
+      while (b < cand.size() && same_sig(cand[a], cand[b])) ++b;
+      if ((int)(b - a) >= kGrpMinLandmarks) {
+        Plan::GrpRange gr;
+        gr.l0 = (int32_t)neworder.size();
+        gr.nl = (int32_t)(b - a);
+        gr.d = deg(cand[a]);
+        pl.grp_range.push_back(gr);
+        for (size_t t = a; t < b; ++t) {
+          grouped[cand[t]] = 1;
+          neworder.push_back(pl.pt_user_of_int[cand[t]]);
+        }
+      }
+      a = b;
+    }
+    pl.M_grp = (int)neworder.size();
+    for (int i = 0; i < M0; ++i)
+      if (!grouped[i]) neworder.push_back(pl.pt_user_of_int[i]);
+    pl.pt_user_of_int.swap(neworder);
+    for (int k = 0; k < M0; ++k) pl.pt_int_of_user[pl.pt_user_of_int[k]] = k;
+  }
   // Interleave inside windows of one Schur super-run: position p of a window
   // takes the landmark p would have had in residue-class order (k = r, r + S,
   // r + 2S, ...), so that every chunk of consecutive landmarks samples the
   // WHOLE window and touches the run's S blocks in the run's proportions
   // (the lanes of the Schur kernel are dealt to the blocks in those proportions).
   if (!(getenv("BA_NO_INTERLEAVE") && getenv("BA_NO_INTERLEAVE")[0] == '1')) {
-    const int W = schur_run_cap(pl.M);
+    const int W = schur_run_cap(pl.M - pl.M_grp);
     std::vector<int32_t> tmp;
-    for (int base = 0; base < pl.M; base += W) {
+    for (int base = pl.M_grp; base < pl.M; base += W) {
       const int n = std::min(W, pl.M - base);
       tmp.clear();
       for (int r = 0; r < kSchurInterleave; ++r)
@@ -464,8 +531,37 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     double sum_max = 0, sum_ideal = 0, sum_mean_active = 0;  // BA_PLAN_STATS
     long n_ch = 0;
     pl.sup_lane.clear();
-    const int sup_cap = schur_run_cap(M);
-    int i = 0;
+    // (a') covisibility groups: one k_schur_grp workgroup per (piece of a) group,
+    // d (d + 1) / 2 slots each, in (jj, kk) row-major order of the upper triangle
+    pl.grp32.clear();
+    pl.grp64.clear();
+    for (const Plan::GrpRange &gr : pl.grp_range) {
+      const int64_t p0 = pl.lm_pair_ptr[gr.l0];
+      for (int l = gr.l0; l < gr.l0 + gr.nl; ++l)
+        if (pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l] != gr.d)
+          return "internal: covisibility group with a ragged landmark";
+      static const int grp_max = getenv("BA_GRP_MAX") ? std::max(12, atoi(getenv("BA_GRP_MAX"))) : kGrpMaxLandmarks;
+      const int pieces = (gr.nl + grp_max - 1) / grp_max;
+      const int per = (gr.nl + pieces - 1) / pieces;
+      for (int c0 = 0; c0 < gr.nl; c0 += per) {
+        Plan::GrpDesc gd;
+        gd.l0 = gr.l0 + c0;
+        gd.nl = std::min(per, gr.nl - c0);
+        gd.d = gr.d;
+        gd.p0 = p0 + (int64_t)gr.d * c0;
+        gd.s0 = (int32_t)pl.slot_blk.size();
+        for (int t = 0; t < kGrpMaxPoses; ++t) gd.pose[t] = t < gr.d ? pl.pair_pose[p0 + t] : 0;
+        for (int jj = 0; jj < gr.d; ++jj)
+          for (int kk = jj; kk < gr.d; ++kk) {
+            const int32_t bk = block_of(gd.pose[jj], gd.pose[kk]);
+            contrib.push_back({bk, (int32_t)pl.slot_blk.size()});
+            pl.slot_blk.push_back(bk);
+          }
+        (gr.d <= 5 ? pl.grp32 : pl.grp64).push_back(gd);
+      }
+    }
+    const int sup_cap = schur_run_cap(M - pl.M_grp);
+    int i = pl.M_grp;
     while (i < M) {
       // ---- grow a super-run ----
       const int i0 = i;

@@ -49,6 +49,12 @@ constexpr int kSchurSuperMin = 32;         // ... lower bound
 constexpr int kSchurRunTarget = 768;       // super-runs aimed at (3 workgroups x 256 CUs)
 constexpr int kSchurInterleave = 32;       // residue classes of the in-window landmark interleave
 constexpr int kSchurSuperChunks = 64;      // chunks per super-run (descriptor table in LDS)
+// Covisibility groups (k_schur_grp): landmarks seen by the IDENTICAL set of
+// optimisable poses.  Their Schur contributions sum_i V_ji W_ki^T are one dense
+// (6d x 3n) (3n x 6d) product per group, which runs on the fp64 matrix cores.
+constexpr int kGrpMaxPoses = 10;    // pose-set sizes handled by the group kernel (<= 5: 32-wide tiles, <= 10: 64-wide)
+constexpr int kGrpMinLandmarks = 24;  // smaller groups stay on the super-run path
+constexpr int kGrpMaxLandmarks = 1024; // landmarks per group workgroup (larger groups are split)
 
 struct Plan {
   // ---- sizes ----
@@ -119,6 +125,16 @@ struct Plan {
   std::vector<int64_t> blk_contrib_ptr;  // B+1 -> contrib_slot
   std::vector<int32_t> contrib_slot;     // slots of each block, workgroup order
   std::vector<int32_t> bchunk_lm;        // landmark ranges of the backsub chunks
+  // ---- covisibility groups: the first M_grp landmarks, ordered by group ----
+  int M_grp = 0;
+  struct GrpRange { int32_t l0, nl, d; };   // landmarks [l0, l0 + nl) share one set of d poses
+  std::vector<GrpRange> grp_range;
+  struct GrpDesc {                       // one k_schur_grp workgroup (64 bytes)
+    int64_t p0;                          // first pair: pair(il, jj) = p0 + d * il + jj
+    int32_t l0, nl, d, s0;               // landmarks, pose count, first of its d (d + 1) / 2 slots
+    int32_t pose[kGrpMaxPoses];          // ascending optimised pose indices
+  };
+  std::vector<GrpDesc> grp32, grp64;     // d <= 5 / 6 <= d <= 10
 };
 
 // Tile pattern of the GLOBAL reduced camera matrix (all shards) for tiles of

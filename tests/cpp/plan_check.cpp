@@ -123,7 +123,55 @@ int main(int argc, char **argv) {
       triples += cd.nt;
     }
   }
-  // every landmark with pairs is covered exactly once, by a super-run or by the big-landmark list
+  // ---- covisibility groups: the first M_grp landmarks, group after group ----
+  int64_t grp_triples = 0;
+  {
+    int next = 0;
+    for (const auto &gr : pl.grp_range) {
+      CHECK(gr.l0 == next && gr.nl >= ba::kGrpMinLandmarks && gr.d >= 1 && gr.d <= ba::kGrpMaxPoses, "group range");
+      next = gr.l0 + gr.nl;
+    }
+    CHECK(next == pl.M_grp && pl.M_grp <= pl.M, "groups tile [0, M_grp)");
+    std::vector<int> gcov(pl.M, 0);
+    for (const auto *list : {&pl.grp32, &pl.grp64})
+      for (const auto &gd : *list) {
+        CHECK((gd.d <= 5) == (list == &pl.grp32), "group filed under the wrong tile width");
+        CHECK(gd.nl >= 1 && gd.nl <= ba::kGrpMaxLandmarks && gd.l0 >= 0 && gd.l0 + gd.nl <= pl.M_grp, "group piece range");
+        CHECK(gd.p0 == pl.lm_pair_ptr[gd.l0], "group pair base");
+        for (int t = 1; t < gd.d; ++t) CHECK(gd.pose[t - 1] < gd.pose[t], "group poses ascend");
+        for (int l = gd.l0; l < gd.l0 + gd.nl; ++l) {
+          gcov[l]++;
+          CHECK(pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l] == gd.d, "group landmark degree");
+          for (int t = 0; t < gd.d; ++t) {
+            const int64_t p = gd.p0 + (int64_t)gd.d * (l - gd.l0) + t;
+            CHECK(pl.pair_lm[p] == l && pl.pair_pose[p] == gd.pose[t], "pair(il, jj) = p0 + d il + jj");
+          }
+        }
+        int idx = 0;
+        for (int jj = 0; jj < gd.d; ++jj)
+          for (int kk = jj; kk < gd.d; ++kk, ++idx) {
+            CHECK(idx == jj * gd.d - jj * (jj - 1) / 2 + (kk - jj), "slot index formula of k_schur_grp");
+            const int blk = pl.slot_blk[gd.s0 + idx];
+            CHECK(pl.sblk_j[blk] == gd.pose[jj] && pl.sblk_k[blk] == gd.pose[kk], "group slot block");
+          }
+        grp_triples += (int64_t)gd.nl * gd.d * (gd.d + 1) / 2;
+      }
+    for (int l = 0; l < pl.M; ++l) {
+      CHECK(gcov[l] == (l < pl.M_grp ? 1 : 0), "landmark %d in %d group pieces", l, gcov[l]);
+      CHECK(!(gcov[l] && covered[l]), "landmark %d in a group and in a super-run", l);
+      covered[l] += gcov[l];
+    }
+    // every slot is named by exactly one contribution entry of its block
+    std::vector<int> slot_seen(pl.slot_blk.size(), 0);
+    for (int64_t bk = 0; bk < pl.B; ++bk)
+      for (int64_t c = pl.blk_contrib_ptr[bk]; c < pl.blk_contrib_ptr[bk + 1]; ++c) {
+        CHECK(pl.slot_blk[pl.contrib_slot[c]] == bk, "contribution list names a foreign slot");
+        slot_seen[pl.contrib_slot[c]]++;
+      }
+    for (size_t sl = 0; sl < slot_seen.size(); ++sl) CHECK(slot_seen[sl] == 1, "slot %zu summed %d times", sl, slot_seen[sl]);
+  }
+  triples += grp_triples;
+  // every landmark with pairs is covered exactly once, by a group, a super-run or the big-landmark list
   int64_t big_triples = 0;
   for (int i = 0; i < pl.M; ++i) {
     const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
@@ -140,8 +188,9 @@ int main(int argc, char **argv) {
   for (size_t c = 0; c + 1 < pl.bchunk_lm.size(); ++c)
     CHECK(pl.bchunk_lm[c] < pl.bchunk_lm[c + 1] && pl.bchunk_lm[c + 1] - pl.bchunk_lm[c] <= ba::kSchurLandmarks,
           "backsub chunk size");
-  std::printf("plan: M=%d P=%lld runs=%zu chunks=%zu triples=%lld (+%lld big)  %s\n", pl.M, (long long)pl.P,
-              pl.sup_desc.size(), pl.chunk_desc.size(), (long long)triples, (long long)big_triples,
+  std::printf("plan: M=%d (grouped %d in %zu+%zu pieces) P=%lld runs=%zu chunks=%zu triples=%lld (%lld in groups, +%lld big)  %s\n",
+              pl.M, pl.M_grp, pl.grp32.size(), pl.grp64.size(), (long long)pl.P, pl.sup_desc.size(),
+              pl.chunk_desc.size(), (long long)triples, (long long)grp_triples, (long long)big_triples,
               g_fail ? "FAILED" : "OK");
   return g_fail ? 1 : 0;
 }

@@ -25,11 +25,15 @@ def plan_check(tmp_path_factory):
 
 
 @pytest.mark.parametrize("args,env", [
-    (["120", "30000", "5", "2"], {}),                       # stereo windows, C3/C4 structure
-    (["40", "3000", "9", "1"], {}),                         # mono, wide windows (C2 structure)
-    (["60", "8000", "5", "2"], {"BA_NO_INTERLEAVE": "1"}),  # plain locality order
-    (["30", "400", "5", "2"], {"BA_SUP_CAP": "7"}),         # tiny runs
-    (["200", "6000", "3", "3"], {"BA_SUP_CAP": "1000"}),    # runs ended by the slot / chunk limits
+    (["120", "30000", "5", "2"], {}),                       # stereo windows, C3/C4 structure: covisibility groups
+    (["40", "3000", "9", "1"], {}),                         # mono, wide windows (C2 structure): 64-wide groups
+    (["30", "40000", "4", "1"], {}),                        # groups larger than one workgroup piece
+    (["120", "30000", "5", "2"], {"BA_NO_GROUPS": "1"}),    # the same through the super-runs only
+    (["40", "3000", "9", "1"], {"BA_NO_GROUPS": "1"}),
+    (["60", "8000", "5", "2"], {"BA_NO_INTERLEAVE": "1", "BA_NO_GROUPS": "1"}),  # plain locality order
+    (["30", "400", "5", "2"], {"BA_SUP_CAP": "7", "BA_NO_GROUPS": "1"}),         # tiny runs
+    (["200", "6000", "3", "3"], {"BA_SUP_CAP": "1000", "BA_NO_GROUPS": "1"}),    # runs ended by the slot / chunk limits
+    (["200", "6000", "3", "3"], {}),                        # groups beside super-runs (groups below 24 stay in runs)
 ])
 def test_plan_invariants(plan_check, args, env):
     r = subprocess.run([plan_check] + args, env=dict(os.environ, **env),
