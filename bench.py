@@ -32,6 +32,12 @@ WORKLOADS = {
     "C2": "C2 mono 6-DoF: 200 poses / 50k landmarks / 500k obs",
     "C3": "C3 stereo 6-DoF: 500 poses / 200k landmarks / 2M obs",
     "C4": "C4 stereo 6-DoF: 1000 poses / 500k landmarks / 5M obs",
+    # off the headline's happy path (not BASELINE configs; measured because the
+    # headline scene avoids these code paths)
+    "W20": "off-path W20 mono: 500 poses / 100k landmarks / 2M obs, 20-pose windows "
+           "(k_schur_partial: global triple list)",
+    "DENSE1K": "off-path DENSE1K mono: 1000 poses / 60k landmarks / 480k obs, 8 random "
+               "views per landmark (fully dense reduced system)",
 }
 
 

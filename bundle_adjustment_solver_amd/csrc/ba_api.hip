@@ -1123,6 +1123,15 @@ int ba_get_dense_info(ba_handle *h, double out4[4]) {
   return 0;
 }
 
+int ba_get_schur_info(ba_handle *h, int64_t out4[4]) {
+  if (!h || !h->finalized || !out4) return fail("ba_get_schur_info: bad argument");
+  out4[0] = (int64_t)h->plan.grp32.size();
+  out4[1] = (int64_t)h->plan.grp64.size();
+  out4[2] = h->plan.M_grp;
+  out4[3] = (int64_t)h->plan.sup_desc.size();
+  return 0;
+}
+
 int ba_get_dropped_pivots(ba_handle *h, int64_t *count, int reset) {
   if (!h || !h->finalized || !count) return fail("ba_get_dropped_pivots: bad argument");
   if (use_device(h)) return -1;

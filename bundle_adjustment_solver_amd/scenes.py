@@ -198,12 +198,78 @@ CONFIGS = {
 }
 
 
+def dense_covisibility_scene(n_pose, n_pt, views, seed, n_fixed=5, pose_noise=0.02,
+                            point_noise=0.1, pixel_sigma=0.0):
+    """Off-the-happy-path scene: the rig circles a cloud of points and every
+    landmark is seen from `views` RANDOM poses (loop closures everywhere), so
+    that with enough landmarks every pair of poses shares some: the reduced
+    camera system has no zero block and the structure-aware solve degenerates
+    to the plain dense sweep.  One camera."""
+    rng = np.random.default_rng(seed)
+    intr = np.array([[FX, FY, CX, CY]])
+    T_cj = np.eye(4)[None]
+    ang = 2 * np.pi * np.arange(n_pose) / n_pose
+    T_wc_true = np.tile(np.eye(4), (n_pose, 1, 1))
+    radius = 12.0
+    for k in range(n_pose):
+        # camera on a circle of radius 12 m, looking at the centre
+        c = np.array([radius * np.cos(ang[k]), radius * np.sin(ang[k]), 0.3 * np.sin(3 * ang[k])])
+        z = -c / np.linalg.norm(c)
+        x = np.cross([0.0, 0.0, 1.0], z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        T_wc_true[k, :3, :3] = np.stack([x, y, z], axis=1)
+        T_wc_true[k, :3, 3] = c
+    X_true = rng.uniform(-2.0, 2.0, (n_pt, 3))
+    T_cw = _inv(T_wc_true)
+    pose = np.stack([rng.choice(n_pose, views, replace=False) for _ in range(n_pt)])
+    pose.sort(axis=1)
+    lm = np.repeat(np.arange(n_pt), views)
+    pj = pose.reshape(-1)
+    Xl = np.einsum("nij,nj->ni", T_cw[pj, :3, :3], X_true[lm]) + T_cw[pj, :3, 3]
+    uv = np.stack([FX * Xl[:, 0] / Xl[:, 2] + CX, FY * Xl[:, 1] / Xl[:, 2] + CY], 1)
+    assert (Xl[:, 2] > 0).all()
+    if pixel_sigma > 0:
+        uv = uv + rng.normal(0, pixel_sigma, uv.shape)
+    order = np.lexsort((lm, pj))
+    T_wc_init = T_wc_true.copy()
+    T_wc_init[n_fixed:, :3, 3] += rng.uniform(-pose_noise, pose_noise, (n_pose - n_fixed, 3))
+    return dict(
+        intr=intr, T_cj=T_cj, T_wc_true=T_wc_true, T_wc_init=T_wc_init,
+        X_true=X_true, X_init=X_true + rng.uniform(-point_noise, point_noise, (n_pt, 3)),
+        pose_fixed=np.arange(n_pose) < n_fixed, pt_fixed=np.zeros(n_pt, bool),
+        obs_cam=np.zeros(lm.size, np.int32), obs_pose=pj[order].astype(np.int32),
+        obs_pt=lm[order].astype(np.int32), obs_uv=uv[order])
+
+
+# configurations OFF the headline's happy path (bench.py --config ...)
+OFFPATH = {
+    # mono, windows of 20 poses: a landmark's 210 block pairs exceed the 128 register
+    # slots of a super-run and its pose set the 10 poses of a covisibility group ->
+    # everything goes through k_schur_partial's global triple list
+    "W20": ("window", (500, 100_000, 20, False, SEED_BASE + 7)),
+    # 1000 poses, every landmark seen from 8 random poses: S is fully dense
+    "DENSE1K": ("dense", (1000, 60_000, 8, SEED_BASE + 8)),
+}
+
+
 def config_scene(name, scale=1.0, pixel_sigma=0.0):
     """Scene of a BASELINE.json config; scale<1 shrinks poses and landmarks
     proportionally (parity-test sizes); pixel_sigma is the measurement noise in
     pixels (0, and a second run at 0.5)."""
     if name == "C1":
         return test_ba_scene(pixel_sigma=pixel_sigma)
+    if name in OFFPATH:
+        kind, par = OFFPATH[name]
+        if kind == "dense":
+            n_pose, n_pt, views, seed = par
+            return dense_covisibility_scene(max(20, int(round(n_pose * scale))),
+                                            max(200, int(round(n_pt * scale))), views, seed,
+                                            pixel_sigma=pixel_sigma)
+        n_pose, n_pt, window, stereo, seed = par
+        return synthetic_ba_scene(max(window + 6, int(round(n_pose * scale))),
+                                  max(16, int(round(n_pt * scale))), window, stereo, seed,
+                                  pixel_sigma=pixel_sigma)
     n_pose, n_pt, window, stereo, seed = CONFIGS[name]
     n_pose = max(window + 6, int(round(n_pose * scale)))
     n_pt = max(16, int(round(n_pt * scale)))

@@ -439,6 +439,14 @@ class BaProblem:
         return dict(fill=out[0], flops=out[1], levels=int(out[2]),
                     npad=int(out[3]))
 
+    def get_schur_info(self):
+        """How the Schur complement is accumulated: covisibility-group workgroups
+        (32- / 64-wide tiles), landmarks they cover, super-runs for the rest."""
+        v = (C.c_int64 * 4)()
+        check(self.lib.ba_get_schur_info(self.h, v), "ba_get_schur_info")
+        return dict(groups32=int(v[0]), groups64=int(v[1]), grouped_landmarks=int(v[2]),
+                    super_runs=int(v[3]))
+
     def get_dropped_pivots(self, reset=False):
         """Non-positive pivots met by the reduced-system Cholesky since lm_begin
         (see include/ba_hip.h: where it differs from the reference's pivoted

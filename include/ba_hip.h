@@ -192,6 +192,12 @@ int ba_get_kernel_ms(ba_handle *h, double *ms_out, int64_t *calls_out, int reset
  * matrix order }. */
 int ba_get_dense_info(ba_handle *h, double out4[4]);
 
+/* How the Schur complement of this shard is accumulated (chosen at ba_finalize):
+ * out4 = { workgroups of the covisibility-group kernel with 32-wide tiles (pose
+ * sets of <= 5 poses), the same with 64-wide tiles (6..10 poses), landmarks
+ * covered by groups, super-runs (every other landmark) }. */
+int ba_get_schur_info(ba_handle *h, int64_t out4[4]);
+
 /* The reduced system is factorised by Cholesky WITHOUT pivoting; the
  * reference uses Eigen's diagonally pivoted LDLT with a pseudo-inverted D
  * (reference :905).  A non-positive pivot (<= 1e-300: a pose without

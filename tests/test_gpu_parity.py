@@ -807,3 +807,50 @@ def test_gauge_free_problem_at_the_lambda_floor(stereo, built):
     assert np.abs(S @ ox.reshape(-1) - rhs).max() < 1e-12 * np.abs(rhs).max()
     o.backup(); o.update()
     assert relerr(g.stage_scalars()[0], o.cost()) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["stereo", "mono", "c1"])
+def test_covisibility_groups_equal_the_super_run_path(kind, built):
+    """k_schur_grp (landmarks with identical pose sets as one dense product on
+    the matrix cores) against the super-run kernel alone (BA_NO_GROUPS=1): same
+    reduced system to roundoff, and the window scenes really take the group path
+    (32-wide tiles for the stereo windows of 5 poses, 64-wide for the mono windows
+    of 10); the wall scene C1 (pose sets of up to 55 poses) has no group."""
+    import os
+    pr = scenes.scaled_problem(small_scene(kind))
+    out = []
+    for flag in ("0", "1"):
+        os.environ["BA_NO_GROUPS"] = flag
+        try:
+            g = make_gpu(pr)
+        finally:
+            os.environ.pop("BA_NO_GROUPS", None)
+        info = g.get_schur_info()
+        g.stage_linearize(2.5, 1.0)
+        g.stage_schur()
+        out.append((info,) + g.get_S())
+    (ia, Sa, ra), (ib, Sb, rb) = out
+    assert ib["grouped_landmarks"] == 0 and ib["groups32"] == ib["groups64"] == 0
+    if kind == "stereo":
+        assert ia["groups32"] > 10 and ia["grouped_landmarks"] > 0.8 * g.M
+    elif kind == "mono":
+        assert ia["groups64"] > 5 and ia["grouped_landmarks"] > 0.8 * g.M
+    else:
+        assert ia["grouped_landmarks"] < 0.2 * g.M
+    assert relerr(Sa, Sb) < 1e-12 and relerr(ra, rb) < 1e-12
+
+
+@pytest.mark.parametrize("name,scale", [("W20", 0.1), ("DENSE1K", 0.06)])
+def test_off_path_configs_match_oracle(name, scale, built):
+    """The two configurations bench.py measures OFF the headline's happy path,
+    at a size the faithful oracle follows: 20-pose windows (every landmark goes
+    through k_schur_partial's global triple list) and random 8-view covisibility
+    (dense reduced system, no covisibility group, natural dense sweep)."""
+    pr = scenes.scaled_problem(scenes.config_scene(name, scale))
+    g, o = _compare_solve(pr, iters=8, tol_par=1e-5)
+    info = g.get_schur_info()
+    if name == "W20":
+        assert info["grouped_landmarks"] == 0   # (a few landmarks near the fixed poses have
+        #                                          < 16 free poses and still fit a super-run)
+    else:
+        assert g.get_dense_info()["fill"] > 0.9
