@@ -26,6 +26,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6  # public MI355X datasheet (not in local guides)
+FP64_MFMA_MEASURED_TFLOPS = 47.9  # v_mfma_f64_16x16x4 issue peak measured on the part (tools/mfma_f64_peak.hip)
+FP64_FMA_MEASURED_TFLOPS = 65.0   # v_fma_f64 issue peak measured on the part (same tool)
 
 WORKLOADS = {
     "C1": "C1 test_ba.cpp stereo scene: 60 poses / 660 landmarks / 34019 obs",
@@ -52,7 +54,7 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
-PMC_SUMMARY = {"C4": "profiles/r01_c4_pmc_fetch_write_v17.txt"}
+PMC_SUMMARY = {"C4": "profiles/r02_c4_pmc_fetch_write_v1.txt"}
 
 
 def pmc_traffic(kernel, config):
@@ -287,22 +289,34 @@ def main():
             O_opt = int((pr["pose_fixed"][pr["obs_pose"]] == 0).sum())
             T = int(p.lib.ba_num_schur_triples(p.h))
             B = int(p.lib.ba_num_schur_blocks(p.h))
+            si = p.get_schur_info()
+            Mg, Pg, Tg = si["grouped_landmarks"], si["grouped_pairs"], si["grouped_triples"]
             # algorithmic HBM bytes per launch of each streaming kernel
             # (every array the kernel must read or write, once)
             kbytes = {
                 "k_cost": 24 * n_obs + 24 * M_glob + 96 * n_pose,
-                "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 96 * P +
-                120 * M_glob,
+                # observation records + points in; compact W, undamped C (48) + b (24) out
+                "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 96 * P + 72 * M_glob,
                 "k_lin_poses": 24 * O_opt + 24 * M_glob,
-                "k_schur_lds": 96 * P + 72 * M_glob + 4 * T,
+                "k_damp_invert": 96 * M_glob,
+                "k_schur_grp": 96 * Pg + 72 * Mg,
+                "k_schur_lds": 96 * (P - Pg) + 72 * (M_glob - Mg) + 4 * (T - Tg),
                 "k_schur_final": 288 * B,
                 "k_backsub_update": 96 * P + 192 * M_glob,
             }
+            # arithmetic of the two Schur kernels: executed MFMA flops of the group
+            # kernel (2048 per v_mfma_f64_16x16x4), FMA flops of the super-run kernel
+            # (63 FMAs per half-slot triple, two half slots)
+            kflops = {"k_schur_grp": 2048.0 * si["group_mfma"],
+                      "k_schur_lds": 2.0 * 126.0 * (T - Tg - si["list_triples"])}
+            peaks = {"k_schur_grp": ("mfma", FP64_MFMA_MEASURED_TFLOPS),
+                     "k_schur_lds": ("fma", FP64_FMA_MEASURED_TFLOPS)}
             tot = {k: v[0] / n_prof for k, v in km.items() if v[1]}
             dense = sum(tot.get(k, 0.0) for k in
                         ("k_chol_diag", "k_chol_trsm", "k_chol_diag_trsm", "k_chol_update",
                          "k_chol_back", "k_chol_level", "k_chol_tail"))
-            dom = max(kbytes, key=lambda k: tot.get(k, 0.0))
+            live = [k for k in kbytes if tot.get(k) and kbytes[k] > 0]
+            dom = max(live, key=lambda k: tot[k])
             dom_ms = tot[dom] / km[dom][1] * n_prof   # average launch duration
             ach = kbytes[dom] / (dom_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(dom, args.config)
@@ -312,21 +326,42 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel": dom, "avg_launch_us": dom_ms * 1e3,
                 "algorithmic_bytes_per_launch": kbytes[dom]}
+            if dom in kflops and kflops[dom] > 0:
+                # the Schur kernels are arithmetic- (matrix-core / LDS-) bound, not
+                # HBM-bound: the honest fraction is against the issue peak measured
+                # on this part (tools/mfma_f64_peak.hip)
+                kind, pk = peaks[dom]
+                tf = kflops[dom] / (dom_ms * 1e-3) / 1e12
+                result["roofline"].update({
+                    "bound": "mfma", "achieved": tf, "peak": pk, "unit": "TFLOP/s",
+                    "frac": tf / pk, "pipe": kind,
+                    "hbm": {"achieved_GBs": ach, "frac": ach / HBM_PEAK_GBS}})
             result["roofline_all_hbm_kernels"] = {
-                k: {"GB/s": round(kbytes[k] / (tot[k] * 1e-3) / 1e9, 1),
+                k: {"us": round(tot[k] * 1e3, 1),
+                    "GB/s": round(kbytes[k] / (tot[k] * 1e-3) / 1e9, 1),
                     "frac": round(kbytes[k] / (tot[k] * 1e-3) / 1e9 /
-                                  HBM_PEAK_GBS, 4)}
-                for k in kbytes if tot.get(k)}
+                                  HBM_PEAK_GBS, 4),
+                    "pmc_traffic_bytes": pmc_traffic(k, args.config)[0]}
+                for k in live}
+            result["roofline_schur_arithmetic"] = {
+                k: {"pipe": peaks[k][0], "TFLOP/s": round(kflops[k] / (tot[k] * 1e-3) / 1e12, 2),
+                    "measured_peak_TFLOP/s": peaks[k][1],
+                    "frac": round(kflops[k] / (tot[k] * 1e-3) / 1e12 / peaks[k][1], 4)}
+                for k in kflops if tot.get(k) and kflops[k] > 0}
+            result["schur_paths"] = si
             result["roofline_dense_solve"] = {
                 "bound": "mfma",
                 "achieved": di["flops"] / (dense * 1e-3) / 1e12 if dense else 0,
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (di["flops"] / (dense * 1e-3) / 1e12 /
                          FP64_MFMA_PEAK_TFLOPS) if dense else 0,
+                "frac_of_measured_peak": (di["flops"] / (dense * 1e-3) / 1e12 /
+                                          FP64_MFMA_MEASURED_TFLOPS) if dense else 0,
+                "us": dense * 1e3,
                 "note": "executed flops of the structure-aware factorisation; "
                         "latency-bound (%d dependent levels); measured fp64 "
-                        "MFMA issue peak on this part: 47.9 TFLOP/s "
-                        "(tools/mfma_f64_peak.hip)" % di["levels"]}
+                        "MFMA issue peak on this part: %.1f TFLOP/s "
+                        "(tools/mfma_f64_peak.hip)" % (di["levels"], FP64_MFMA_MEASURED_TFLOPS)}
 
     # ---- CPU baseline: the oracle on the box's host cores, 1 thread -------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1005,7 +1005,9 @@ int ba_get_Cinv(ba_handle *h, double *Cinv9, double *Cinvb3) {
   // Cinv_i b_i is not stored on the device (k_backsub_update forms it): same expression here
   const ba::Plan &pl = h->plan;
   std::vector<double> s6, b3;
+  join_side(h);
   if (pull_ctrl(h)) return -1;
+  ba::launch_damp_invert_export(h->d, h->stream);  // (the LM loop keeps Cinv in registers where it can)
   if (download(s6, h->d.Cinv, (size_t)pl.M * 6, h->stream)) return -1;
   if (download(b3, h->d.b[h->hc.lcur], (size_t)pl.M * 3, h->stream)) return -1;
   for (int i = 0; i < pl.M; ++i) {
@@ -1123,12 +1125,29 @@ int ba_get_dense_info(ba_handle *h, double out4[4]) {
   return 0;
 }
 
-int ba_get_schur_info(ba_handle *h, int64_t out4[4]) {
-  if (!h || !h->finalized || !out4) return fail("ba_get_schur_info: bad argument");
-  out4[0] = (int64_t)h->plan.grp32.size();
-  out4[1] = (int64_t)h->plan.grp64.size();
-  out4[2] = h->plan.M_grp;
-  out4[3] = (int64_t)h->plan.sup_desc.size();
+int ba_get_schur_info(ba_handle *h, int64_t out8[8]) {
+  if (!h || !h->finalized || !out8) return fail("ba_get_schur_info: bad argument");
+  const ba::Plan &pl = h->plan;
+  int64_t pairs = 0, triples = 0, mfma = 0;
+  for (const auto *list : {&pl.grp32, &pl.grp64})
+    for (const auto &g : *list) {
+      pairs += (int64_t)g.nl * g.d;
+      triples += (int64_t)g.nl * g.d * (g.d + 1) / 2;
+      // v_mfma_f64_16x16x4 instructions of k_schur_grp: chunks of nlw landmarks,
+      // ceil(3 nlc / 4) k steps each, NT (NT + 1) / 2 tiles per step
+      const int nt = list == &pl.grp32 ? 2 : 4, krw = nt == 2 ? 36 : 20;
+      const int nlw = std::min(64 / g.d, krw / 3);
+      for (int c0 = 0; c0 < g.nl; c0 += nlw)
+        mfma += (int64_t)((3 * std::min(nlw, g.nl - c0) + 3) / 4) * (nt * (nt + 1) / 2);
+    }
+  out8[0] = (int64_t)pl.grp32.size();
+  out8[1] = (int64_t)pl.grp64.size();
+  out8[2] = pl.M_grp;
+  out8[3] = (int64_t)pl.sup_desc.size();
+  out8[4] = pairs;
+  out8[5] = triples;
+  out8[6] = mfma;
+  out8[7] = (int64_t)pl.tri_p.size();
   return 0;
 }
 

@@ -558,7 +558,14 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d, int s
           const int li = t / 9, v = t - li * 9;
           const int a = max(lq[li], o0), b = min(lq[li + 1], o0 + kBlock);
           double sacc = 0.0;
-          for (int q = a; q < b; ++q) sacc += Cb[(q - o0) * 9 + v];
+          // same insertion order, four LDS reads requested before the first add
+          const double *cp = Cb + (a - o0) * 9 + v;
+          int n = b - a;
+          for (; n >= 4; n -= 4, cp += 36) {
+            const double v0 = cp[0], v1 = cp[9], v2 = cp[18], v3 = cp[27];
+            sacc = (((sacc + v0) + v1) + v2) + v3;
+          }
+          for (; n > 0; --n, cp += 9) sacc += cp[0];
           csum[k] += sacc;
         }
       }
@@ -1126,6 +1133,8 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
   if (done) return;
   const double *__restrict__ Wg = d.W[lb];
   const double *__restrict__ bg = d.b[lb];
+  const double *__restrict__ Cug = d.Cu[lb];
+  const double lp1 = 1.0 + d.ctrl->lambda;
   const int dd = gd.d;
   const int nlw = min(64 / dd, KRW / 3);       // landmarks per wave chunk
   const int il = lane / dd, jj = lane - il * dd;  // this lane's pair inside a chunk
@@ -1145,7 +1154,7 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
     const bool on_ = il < min(nlw, gd.nl - c0_);                                    \
     const double2 *wp_ = (const double2 *)(Wg + (size_t)(gd.p0 + (int64_t)c0_ * dd + (on_ ? lane : 0)) * kWStride); \
     const int lm_ = gd.l0 + c0_ + (on_ ? il : 0);                                   \
-    const double2 *cp_ = (const double2 *)(d.Cinv + (size_t)lm_ * 6);               \
+    const double2 *cp_ = (const double2 *)(Cug + (size_t)lm_ * 6);                  \
     _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) rw[B][k_] = wp_[k_];           \
     _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) rc[B][k_] = cp_[k_];           \
     _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) rb[B][k_] = bg[(size_t)lm_ * 3 + k_]; \
@@ -1165,7 +1174,11 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
       const double k9[9] = {rw[B][0].x, rw[B][0].y, rw[B][1].x, rw[B][1].y, rw[B][2].x, \
                             rw[B][2].y, rw[B][3].x, rw[B][3].y, rw[B][4].x};        \
       const double x0 = rw[B][4].y, x1 = rw[B][5].x, x2 = rw[B][5].y;               \
-      const double c6[6] = {rc[B][0].x, rc[B][0].y, rc[B][1].x, rc[B][1].y, rc[B][2].x, rc[B][2].y}; \
+      /* damping and the 3x3 inverse (reference :846-856) in the lane: the d lanes of a \
+         landmark repeat it, which is cheaper than a kernel + an array for Cinv */    \
+      const double cd_[6] = {rc[B][0].x * lp1, rc[B][0].y, rc[B][1].x, rc[B][1].y * lp1, rc[B][2].x, rc[B][2].y * lp1}; \
+      double c6[6];                                                                 \
+      ldlt3_inverse(cd_, c6);                                                       \
       double w[18];                                                                 \
       _Pragma("unroll") for (int e = 0; e < 9; ++e) w[e] = k9[e];                   \
       _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
@@ -1441,6 +1454,96 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
   d.L[(size_t)col * d.ld + row] = val;
 }
 
+// se3 exponential (reference :1046-1082) composed onto T_jw (:487-494),
+// pose-side model terms (:437-441) and sum |x_j| (:962).  Block b writes its
+// partial sums to pose_part[2 + 2b ..]; k_scalars adds them in block order.
+// Runs as the first kPoseGrid workgroups of the k_backsub_update launch (it needs
+// x only, like the back-substitution): no launch, no stream fork of its own.
+__device__ __forceinline__ void pose_update_body(const DevProblem &d, const int bid, double *sm) {
+  const int cur = d.ctrl->cur;
+  const int lbp = d.ctrl->lcur;
+  const double lp1p = 1.0 + d.ctrl->lambda;
+  if (bid == 0 && threadIdx.x == 0) {  // buffers of this iteration's trial point
+    d.ctrl->tcur = cur ^ 1;
+    d.ctrl->tlcur = lbp ^ 1;
+  }
+  const double *__restrict__ Tc = d.poses[cur];
+  double *__restrict__ Tt = d.poses[cur ^ 1];
+  double est = 0.0, nrm = 0.0;
+  for (int j = bid * kBlock + threadIdx.x; j < d.N; j += kPoseGrid * kBlock) {
+    const double *xj = d.x + (size_t)j * 6;
+    const double v0 = xj[0], v1 = xj[1], v2 = xj[2];
+    const double w0 = xj[3], w1 = xj[4], w2 = xj[5];
+    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    const double wx[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double wx2[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        wx2[r * 3 + c] = wx[r * 3 + 0] * wx[0 * 3 + c] +
+                         wx[r * 3 + 1] * wx[1 * 3 + c] +
+                         wx[r * 3 + 2] * wx[2 * 3 + c];
+    double ca, cb, va, vb;
+    if (theta < 1e-7) {
+      ca = 1.0;
+      cb = 0.5;
+      va = 0.5;
+      vb = 0.33333333333333333333333333;
+    } else {
+      const double st = sin(theta), ct = cos(theta);
+      ca = st / theta;
+      cb = (1.0 - ct) / (theta * theta);
+      va = cb;
+      vb = (theta - st) / (theta * theta * theta);
+    }
+    double dR[9], V[9], dt[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double id = (k % 4 == 0) ? 1.0 : 0.0;
+      dR[k] = id + ca * wx[k] + cb * wx2[k];
+      V[k] = id + va * wx[k] + vb * wx2[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      dt[r] = V[r * 3 + 0] * v0 + V[r * 3 + 1] * v1 + V[r * 3 + 2] * v2;
+    const double *T = Tc + (size_t)j * 12;
+    double *To = Tt + (size_t)j * 12;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        To[r * 3 + c] = dR[r * 3 + 0] * T[0 * 3 + c] +
+                        dR[r * 3 + 1] * T[1 * 3 + c] +
+                        dR[r * 3 + 2] * T[2 * 3 + c];
+      To[9 + r] = dR[r * 3 + 0] * T[9] + dR[r * 3 + 1] * T[10] +
+                  dR[r * 3 + 2] * T[11] + dt[r];
+    }
+    const double *aj = d.a[lbp] + (size_t)j * 6;
+    const double *Aj = d.A[lbp] + (size_t)j * 36;
+    double e = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) e += aj[r] * xj[r];
+    double q = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double rowc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)  // damped A_j (reference :833-844)
+        rowc += xj[r] * (r == c ? Aj[r * 6 + c] * lp1p : Aj[r * 6 + c]);
+      q += rowc * xj[c];
+    }
+    est += e + q;
+    nrm += sqrt(v0 * v0 + v1 * v1 + v2 * v2 + w0 * w0 + w1 * w1 + w2 * w2);
+  }
+  const double t0 = block_sum(est, sm);
+  const double t1 = block_sum(nrm, sm);
+  if (threadIdx.x == 0) {
+    d.pose_part[2 + 2 * bid + 0] = t0;
+    d.pose_part[2 + 2 * bid + 1] = t1;
+  }
+}
+
 // y_i, trial point, landmark-side model terms and |y_i|.
 // y_i = Cinv_i b_i - Cinv_i (sum_j B_ji^T x_j)  (reference :910-917; CinvBt is
 // never materialised) — the same vector sum_j B_ji^T x_j is the cross term of
@@ -1498,11 +1601,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
   const int tid = threadIdx.x;
 #ifdef BA_BS_DBG
   __shared__ long long bs_s[96];
-  const bool bs_on = blockIdx.x == 2000 && threadIdx.x == 0;
+  const bool bs_on = blockIdx.x == 2000 + kPoseGrid && threadIdx.x == 0;
   int bs_n = 0;
 #endif
   BS_STAMP()
-  const int c0 = blockIdx.x * kBsChunks;
+  if (blockIdx.x < kPoseGrid) {  // pose role (wave-uniform): see pose_update_body
+    if (d.ctrl->done) return;
+    pose_update_body(d, blockIdx.x, sm);
+    return;
+  }
+  const int bx = blockIdx.x - kPoseGrid;
+  const int c0 = bx * kBsChunks;
   const int nk = min(kBsChunks, d.n_bchunk - c0);
   // the workgroup's chunk records -> LDS (vector loads), first one also scalar
   const DevProblem::LmChunk lc0 = d.lm_chunk[c0];
@@ -1550,8 +1659,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
     if (own) {
       q0 = d.lm_pair_ptr[i];
       q1 = d.lm_pair_ptr[i + 1];
-#pragma unroll
-      for (int e = 0; e < 6; ++e) ci[e] = d.Cinv[(size_t)i * 6 + e];
 #pragma unroll
       for (int e = 0; e < 3; ++e) Xi[e] = Xc[(size_t)i * 3 + e];
 #pragma unroll
@@ -1630,7 +1737,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
     }
     double est = 0.0, nrm = 0.0;
     if (own) {
-      // Cinv_i b_i (reference :855), formed here instead of being stored
+      // damping and inverse (reference :846-856), then Cinv_i b_i (:855): formed
+      // here from the undamped C_i instead of being read
+      {
+        const double cdm[6] = {C[0] * lp1, C[1], C[2], C[3] * lp1, C[4], C[5] * lp1};
+        ldlt3_inverse(cdm, ci);
+      }
       const double cb0 = ci[0] * bi[0] + ci[1] * bi[1] + ci[2] * bi[2];
       const double cb1 = ci[1] * bi[0] + ci[3] * bi[1] + ci[4] * bi[2];
       const double cb2 = ci[2] * bi[0] + ci[4] * bi[1] + ci[5] * bi[2];
@@ -1661,8 +1773,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
   // one pair of partial sums per workgroup (k_scalars adds them in block order)
   block_sum2(est_acc, nrm_acc, sm);
   if (tid == 0) {
-    d.lm_part[2 * blockIdx.x + 0] = est_acc;
-    d.lm_part[2 * blockIdx.x + 1] = nrm_acc;
+    d.lm_part[2 * bx + 0] = est_acc;
+    d.lm_part[2 * bx + 1] = nrm_acc;
   }
   BS_STAMP()
 #ifdef BA_BS_DBG
@@ -1674,96 +1786,6 @@ extern "C" int ba_debug_read_bs(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_dbg), sizeof(long long) * 96);
 }
 #endif
-
-// se3 exponential (reference :1046-1082) composed onto T_jw (:487-494),
-// pose-side model terms (:437-441) and sum |x_j| (:962).  Block b writes its
-// partial sums to pose_part[2 + 2b ..]; k_scalars adds them in block order.
-__global__ __launch_bounds__(kBlock) void k_pose_update(DevProblem d) {
-  if (d.ctrl->done) return;
-  __shared__ double sm[4];
-  const int cur = d.ctrl->cur;
-  const int lbp = d.ctrl->lcur;
-  const double lp1p = 1.0 + d.ctrl->lambda;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // buffers of this iteration's trial point
-    d.ctrl->tcur = cur ^ 1;
-    d.ctrl->tlcur = lbp ^ 1;
-  }
-  const double *__restrict__ Tc = d.poses[cur];
-  double *__restrict__ Tt = d.poses[cur ^ 1];
-  double est = 0.0, nrm = 0.0;
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.N; j += gridDim.x * kBlock) {
-    const double *xj = d.x + (size_t)j * 6;
-    const double v0 = xj[0], v1 = xj[1], v2 = xj[2];
-    const double w0 = xj[3], w1 = xj[4], w2 = xj[5];
-    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
-    const double wx[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
-    double wx2[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        wx2[r * 3 + c] = wx[r * 3 + 0] * wx[0 * 3 + c] +
-                         wx[r * 3 + 1] * wx[1 * 3 + c] +
-                         wx[r * 3 + 2] * wx[2 * 3 + c];
-    double ca, cb, va, vb;
-    if (theta < 1e-7) {
-      ca = 1.0;
-      cb = 0.5;
-      va = 0.5;
-      vb = 0.33333333333333333333333333;
-    } else {
-      const double st = sin(theta), ct = cos(theta);
-      ca = st / theta;
-      cb = (1.0 - ct) / (theta * theta);
-      va = cb;
-      vb = (theta - st) / (theta * theta * theta);
-    }
-    double dR[9], V[9], dt[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double id = (k % 4 == 0) ? 1.0 : 0.0;
-      dR[k] = id + ca * wx[k] + cb * wx2[k];
-      V[k] = id + va * wx[k] + vb * wx2[k];
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      dt[r] = V[r * 3 + 0] * v0 + V[r * 3 + 1] * v1 + V[r * 3 + 2] * v2;
-    const double *T = Tc + (size_t)j * 12;
-    double *To = Tt + (size_t)j * 12;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        To[r * 3 + c] = dR[r * 3 + 0] * T[0 * 3 + c] +
-                        dR[r * 3 + 1] * T[1 * 3 + c] +
-                        dR[r * 3 + 2] * T[2 * 3 + c];
-      To[9 + r] = dR[r * 3 + 0] * T[9] + dR[r * 3 + 1] * T[10] +
-                  dR[r * 3 + 2] * T[11] + dt[r];
-    }
-    const double *aj = d.a[lbp] + (size_t)j * 6;
-    const double *Aj = d.A[lbp] + (size_t)j * 36;
-    double e = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) e += aj[r] * xj[r];
-    double q = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      double rowc = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)  // damped A_j (reference :833-844)
-        rowc += xj[r] * (r == c ? Aj[r * 6 + c] * lp1p : Aj[r * 6 + c]);
-      q += rowc * xj[c];
-    }
-    est += e + q;
-    nrm += sqrt(v0 * v0 + v1 * v1 + v2 * v2 + w0 * w0 + w1 * w1 + w2 * w2);
-  }
-  const double t0 = block_sum(est, sm);
-  const double t1 = block_sum(nrm, sm);
-  if (threadIdx.x == 0) {
-    d.pose_part[2 + 2 * blockIdx.x + 0] = t0;
-    d.pose_part[2 + 2 * blockIdx.x + 1] = t1;
-  }
-}
 
 // Reduce the block partials into the exchange scalars.
 //   mode 0: scal[0] = cost only (initial cost)
@@ -1979,7 +2001,9 @@ void launch_lin_poses(const DevProblem &d, int sel, hipStream_t s) {
 }
 
 void launch_damp_invert(const DevProblem &d, hipStream_t s) {
-  if (d.M > 0)
+  // Cinv as an ARRAY is read by the super-run and triple-list Schur kernels only:
+  // the covisibility-group kernel and the back-substitution invert in registers
+  if (d.M > 0 && (d.n_sup > 0 || d.n_tchunk > 0))
     BA_LAUNCH(K_DAMP_INVERT, k_damp_invert, dim3(cdiv(d.M, kBlock)), dim3(kBlock), s, d, 0);
 }
 // reader variant: also stores the damped C_i (ba_get_C)
@@ -2036,9 +2060,8 @@ void launch_scatter(const DevProblem &d, hipStream_t s) {
 }
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s) {
-  if (d.n_bchunk > 0)
-    BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(cdiv(d.n_bchunk, kBsChunks)), dim3(kBlock), s, d);
-  BA_LAUNCH(K_POSE_UPDATE, k_pose_update, dim3(kPoseGrid), dim3(kBlock), s, d);
+  // the first kPoseGrid workgroups update the poses, the others back-substitute
+  BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(kPoseGrid + cdiv(d.n_bchunk, kBsChunks)), dim3(kBlock), s, d);
 }
 
 void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s) {

@@ -442,10 +442,11 @@ class BaProblem:
     def get_schur_info(self):
         """How the Schur complement is accumulated: covisibility-group workgroups
         (32- / 64-wide tiles), landmarks they cover, super-runs for the rest."""
-        v = (C.c_int64 * 4)()
+        v = (C.c_int64 * 8)()
         check(self.lib.ba_get_schur_info(self.h, v), "ba_get_schur_info")
         return dict(groups32=int(v[0]), groups64=int(v[1]), grouped_landmarks=int(v[2]),
-                    super_runs=int(v[3]))
+                    super_runs=int(v[3]), grouped_pairs=int(v[4]), grouped_triples=int(v[5]),
+                    group_mfma=int(v[6]), list_triples=int(v[7]))
 
     def get_dropped_pivots(self, reset=False):
         """Non-positive pivots met by the reduced-system Cholesky since lm_begin

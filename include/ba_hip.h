@@ -193,10 +193,13 @@ int ba_get_kernel_ms(ba_handle *h, double *ms_out, int64_t *calls_out, int reset
 int ba_get_dense_info(ba_handle *h, double out4[4]);
 
 /* How the Schur complement of this shard is accumulated (chosen at ba_finalize):
- * out4 = { workgroups of the covisibility-group kernel with 32-wide tiles (pose
+ * out8 = { workgroups of the covisibility-group kernel with 32-wide tiles (pose
  * sets of <= 5 poses), the same with 64-wide tiles (6..10 poses), landmarks
- * covered by groups, super-runs (every other landmark) }. */
-int ba_get_schur_info(ba_handle *h, int64_t out4[4]);
+ * covered by groups, super-runs (the other landmarks), (landmark, pose) pairs in
+ * groups, Schur triples in groups, v_mfma_f64_16x16x4 instructions the group
+ * kernel executes per launch, triples on the global list (landmarks too large
+ * for a super-run) }. */
+int ba_get_schur_info(ba_handle *h, int64_t out8[8]);
 
 /* The reduced system is factorised by Cholesky WITHOUT pivoting; the
  * reference uses Eigen's diagonally pivoted LDLT with a pseudo-inverted D

@@ -163,7 +163,7 @@ def test_documents_cite_existing_profile_files():
     cited = set()
     for name in ("DESIGN.md", "README.md", "bench.py", "profiles/README.md"):
         text = open(os.path.join(root, name)).read()
-        cited |= set(re.findall(r"profiles/(r01_[A-Za-z0-9_{},.]+?\.(?:json|csv|txt))", text))
+        cited |= set(re.findall(r"profiles/(r0[0-9]_[A-Za-z0-9_{},.]+?\.(?:json|csv|txt))", text))
     assert cited
     for c in sorted(cited):
         m = re.search(r"\{([^}]*)\}", c)

@@ -1,6 +1,23 @@
+#!/bin/bash
+# One gpurun call behind a profiles/ set:   tools/collect_profiles.sh <tag>   (e.g. r02_v1)
+# default bench (C4) + the sigma = 0.5 px second run of SURVEY.md 8(d), rocprofv3 kernel trace,
+# separate --pmc FETCH_SIZE / WRITE_SIZE passes, C1-C3 + the two off-path configs, pose-only
+# latency, the dense sweep beside the rocSOLVER comparator.  Outputs under gpurun_out/<tag>_*.
+T=${1:-r02_v1}
+O=gpurun_out
 export TMPDIR=/tmp
-python bench.py > gpurun_out/bench_c4_v17.json 2> gpurun_out/bench_c4_v17.err && \
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_v17 --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof_v17.log 2>&1 && \
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_v17 --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_fetch_v17.log 2>&1 && \
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write_v17 --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_write_v17.log 2>&1 && \
-python bench.py --config C3 --no-cpu-baseline > gpurun_out/bench_c3_v17.json 2>/dev/null && python bench.py --config C2 --no-cpu-baseline > gpurun_out/bench_c2_v17.json 2>/dev/null && python bench.py --config C1 --no-cpu-baseline > gpurun_out/bench_c1_v17.json 2>/dev/null; python tools/pose_only_bench.py > gpurun_out/pose_only_v17.log 2>&1; echo done
+python bench.py > $O/${T}_c4_bench.json 2> $O/${T}_c4_bench.err && \
+python bench.py --sigma 0.5 --no-cpu-baseline > $O/${T}_c4_sigma05_bench.json 2> /dev/null && \
+rocprofv3 --kernel-trace --stats -d $O/prof_$T --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof_$T.log 2>&1 && \
+python tools/timeline.py $O/prof_$T > $O/${T}_c4_timeline.txt 2>&1 && \
+cp $O/prof_$T/*/*kernel_stats.csv $O/${T}_c4_kernel_stats.csv && rm -f $O/prof_$T/*/*kernel_trace.csv && \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$T --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch_$T.log 2>&1 && \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$T --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write_$T.log 2>&1 && \
+python tools/pmc_summary.py $O/pmc_fetch_$T $O/pmc_write_$T > $O/${T}_c4_pmc_fetch_write.txt 2>&1 && \
+rm -rf $O/pmc_fetch_$T $O/pmc_write_$T && \
+for c in C3 C2 C1 W20 DENSE1K; do python bench.py --config $c --no-cpu-baseline > $O/${T}_$(echo $c | tr A-Z a-z)_bench.json 2>/dev/null; done
+python tools/pose_only_bench.py > $O/${T}_c5_pose_only.txt 2>&1
+python tools/dense_bench.py --n 5970 > $O/${T}_dense_sweep.txt 2>&1
+tools/rocsolver_bench 5970 5 >> $O/${T}_dense_sweep.txt 2>&1
+./cpp/build/test_compare > $O/${T}_c5_compare_autodiff_lm.txt 2>&1
+echo done
