@@ -182,8 +182,8 @@ def main():
                        pr["obs_uv"])
     keep = []
     if world > 1:
-        p.set_shard(rank, world)
-        p.set_stream(torch.cuda.current_stream().cuda_stream)
+        p.set_shard(rank, world)   # (the handle keeps its own stream: the exchange
+        #                            hook is told which one, see sharding.TorchExchange)
     t_fin = time.time()
     p.finalize()
     t_fin = time.time() - t_fin
@@ -221,6 +221,9 @@ def main():
         elapsed = float(te.item())
     rows, n_done, conv, done = p.lm_sync(cap=args.warmup + args.steps + 1)
     assert n_done == args.warmup + args.steps, (n_done, args)
+    if os.environ.get("BA_BENCH_DUMP_ROWS"):  # developer aid: the trajectory of every rank
+        sys.stderr.write("rank %d: %s\n" % (rank, " ".join(
+            "%d:%.6g" % (r.iteration_status, r.trial_cost) for r in rows)))
 
     ms_per_step = elapsed / args.steps * 1e3
     result = {

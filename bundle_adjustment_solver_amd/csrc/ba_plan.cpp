@@ -474,16 +474,22 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       return (int32_t)(std::lower_bound(b0, e0, k) - &pl.sblk_k[0]);
     };
 
+    // does not fit a super-run whole ...
     auto is_big = [&](int64_t d) {
       return d * (d + 1) / 2 > kSchurTri || d * (d + 1) / 2 > kSchurSlots ||
              d > kSchurPairs;
+    };
+    // ... and cannot be split into classes either (its pairs exceed the LDS staging): global list
+    auto is_list = [&](int64_t d) {
+      static const bool no_split = getenv("BA_NO_SPLIT") && getenv("BA_NO_SPLIT")[0] == '1';
+      return is_big(d) && (d > kSchurPairs || no_split);
     };
     // (a) big landmarks -> global triple list sorted by (block, landmark)
     int64_t Tbig = 0, Tall = 0;
     for (int i = 0; i < M; ++i) {
       const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
       Tall += d * (d + 1) / 2;
-      if (is_big(d)) Tbig += d * (d + 1) / 2;
+      if (is_list(d)) Tbig += d * (d + 1) / 2;
     }
     pl.T = Tall;
     {
@@ -491,7 +497,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       big.reserve(Tbig);
       for (int i = 0; i < M; ++i) {
         const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
-        if (!is_big(p1 - p0)) continue;
+        if (!is_list(p1 - p0)) continue;
         for (int64_t p = p0; p < p1; ++p)
           for (int64_t q = p; q < p1; ++q)
             big.push_back({block_of(pl.pair_pose[p], pl.pair_pose[q]), {p, q}});
@@ -561,22 +567,47 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       }
     }
     const int sup_cap = schur_run_cap(M - pl.M_grp);
-    int i = pl.M_grp;
-    while (i < M) {
+    // Landmark kinds: 0 = fits a super-run whole; 1 = SPLIT: its pairs fit the LDS
+    // staging (<= kSchurPairs) but its d (d + 1) / 2 blocks exceed the kSchurSlots
+    // register slots of a run: the pose list is cut into g groups of <= kSplit
+    // poses and the landmark is processed once per CLASS (a, b), a <= b < g — the
+    // triples (p, q) with p in group a and q in group b: at most kSplit^2 <= 128
+    // blocks — in a separate run; 2 = big (more pairs than the staging holds):
+    // global triple list.
+    constexpr int kSplit = 11;
+    static_assert(kSplit * kSplit <= kSchurSlots && kSplit * kSplit <= kSchurTri, "class size");
+    auto kind_of = [&](int l) {
+      const int64_t d = pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l];
+      if (!is_big(d)) return 0;
+      return is_list(d) ? 2 : 1;
+    };
+    auto ngrp = [&](int l) { return (int)((pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l] + kSplit - 1) / kSplit); };
+    // triples of landmark l in class (ca, cb) of split size sp (sp == 0: all)
+    auto class_triples = [&](int l, int sp, int ca, int cb) -> int64_t {
+      const int64_t d = pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l];
+      if (sp == 0) return d * (d + 1) / 2;
+      const int64_t na = std::min<int64_t>(sp, d - (int64_t)ca * sp), nb = std::min<int64_t>(sp, d - (int64_t)cb * sp);
+      if (na <= 0 || nb <= 0) return 0;
+      return ca == cb ? na * (na + 1) / 2 : na * nb;
+    };
+    auto in_class = [&](int64_t lp, int64_t lq, int sp, int ca, int cb) {
+      return sp == 0 || (lp / sp == ca && lq / sp == cb);
+    };
+    std::string run_error;
+    // super-runs over the landmarks [lo, hi) (all of one kind), restricted to one class
+    auto build_runs = [&](const int lo, const int hi, const int sp, const int ca, const int cb) {
+    int i = lo;
+    while (i < hi && run_error.empty()) {
       // ---- grow a super-run ----
       const int i0 = i;
       sup_blocks.clear();
       // chunk count of the run so far (same greedy rule as the chunk loop below)
       int nchunk = 1, cnl = 0;
       int64_t cnp = 0, cnt = 0;
-      while (i < M && i - i0 < sup_cap) {
+      while (i < hi && i - i0 < sup_cap) {
         const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
-        if (is_big(p1 - p0)) {
-          if (i == i0) ++i;  // big landmark alone (handled by the triple list)
-          break;
-        }
         {
-          const int64_t dd = p1 - p0, dt = dd * (dd + 1) / 2;
+          const int64_t dd = p1 - p0, dt = class_triples(i, sp, ca, cb);
           if (cnl > 0 && (cnp + dd > kSchurPairs || cnt + dt > kSchurTri ||
                           cnl >= kSchurLandmarks)) {
             if (nchunk == kSchurSuperChunks) break;  // descriptor table in LDS is full
@@ -592,6 +623,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         const size_t before = sup_blocks.size();
         for (int64_t p = p0; p < p1; ++p)
           for (int64_t q = p; q < p1; ++q) {
+            if (!in_class(p - p0, q - p0, sp, ca, cb)) continue;
             const int32_t bk = block_of(pl.pair_pose[p], pl.pair_pose[q]);
             if (mark[bk] < 0) {
               mark[bk] = (int32_t)sup_blocks.size();
@@ -599,7 +631,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
             }
           }
         if ((int)sup_blocks.size() > kSchurSlots && i > i0) {
-          for (size_t s = before; s < sup_blocks.size(); ++s) mark[sup_blocks[s]] = -1;
+          for (size_t s2 = before; s2 < sup_blocks.size(); ++s2) mark[sup_blocks[s2]] = -1;
           sup_blocks.resize(before);
           break;
         }
@@ -607,29 +639,25 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       }
       const int i1 = i;
       const int ns = (int)sup_blocks.size();
-      bool any = false;
-      for (int l = i0; l < i1; ++l)
-        any = any || !is_big(pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l]);
-      if (!any || ns == 0) {
-        for (int32_t bk : sup_blocks) mark[bk] = -1;
+      if (ns == 0) {  // landmarks without pairs
         continue;
       }
-      if (ns > kSchurSlots) {  // one landmark with too many blocks: cannot be
-        // register-resident -> leave it to the global triple list
+      if (ns > kSchurSlots) {
         for (int32_t bk : sup_blocks) mark[bk] = -1;
-        return "internal: landmark exceeds kSchurSlots blocks but not kSchurTri";
+        run_error = "internal: landmark class exceeds kSchurSlots blocks";
+        return;
       }
       // slots sorted by block id for a stable order
       std::vector<int32_t> order(sup_blocks);
       std::sort(order.begin(), order.end());
-      for (int s = 0; s < ns; ++s) mark[order[s]] = s;
+      for (int s2 = 0; s2 < ns; ++s2) mark[order[s2]] = s2;
       Plan::SupDesc sd;
       sd.s0 = (int32_t)pl.slot_blk.size();
       sd.ns = ns;
       sd.chunk_begin = (int32_t)pl.chunk_desc.size();
-      for (int s = 0; s < ns; ++s) {
-        contrib.push_back({order[s], sd.s0 + s});
-        pl.slot_blk.push_back(order[s]);
+      for (int s2 = 0; s2 < ns; ++s2) {
+        contrib.push_back({order[s2], sd.s0 + s2});
+        pl.slot_blk.push_back(order[s2]);
       }
       // ---- chunks ----
       tcount.assign(ns, 0);
@@ -640,7 +668,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         int64_t np = 0, nt = 0;
         while (l < i1) {
           const int64_t d = pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l];
-          const int64_t dt = d * (d + 1) / 2;
+          const int64_t dt = class_triples(l, sp, ca, cb);
           if (l > c0 && (np + d > kSchurPairs || nt + dt > kSchurTri ||
                          l - c0 >= kSchurLandmarks))
             break;
@@ -649,12 +677,16 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           ++l;
         }
         loc.clear();
-        for (int m = c0; m < l; ++m)
-          for (int64_t p = pl.lm_pair_ptr[m]; p < pl.lm_pair_ptr[m + 1]; ++p)
+        for (int m = c0; m < l; ++m) {
+          const int64_t q0 = pl.lm_pair_ptr[m];
+          for (int64_t p = q0; p < pl.lm_pair_ptr[m + 1]; ++p)
             for (int64_t q = p; q < pl.lm_pair_ptr[m + 1]; ++q)
-              loc.push_back({mark[block_of(pl.pair_pose[p], pl.pair_pose[q])],
-                             (uint32_t)(((p - pbase) << 16) | ((uint32_t)(m - c0) << 8) |
-                                        (q - pbase))});
+              if (in_class(p - q0, q - q0, sp, ca, cb))
+                loc.push_back({mark[block_of(pl.pair_pose[p], pl.pair_pose[q])],
+                               (uint32_t)(((p - pbase) << 16) | ((uint32_t)(m - c0) << 8) |
+                                          (q - pbase))});
+        }
+        if (loc.empty()) continue;  // (landmarks without pairs)
         std::stable_sort(loc.begin(), loc.end(),
                          [](const auto &x, const auto &y) { return x.first < y.first; });
         Plan::ChunkDesc cd;
@@ -668,8 +700,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         cd.nt = (int32_t)loc.size();
         // per-slot offsets into this chunk's triple list
         size_t t = 0;
-        for (int s = 0; s <= ns; ++s) {
-          while (t < loc.size() && loc[t].first < s) ++t;
+        for (int s2 = 0; s2 <= ns; ++s2) {
+          while (t < loc.size() && loc[t].first < s2) ++t;
           pl.chunk_sp.push_back((uint16_t)t);
         }
         for (auto &e : loc) {
@@ -679,8 +711,18 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         pl.chunk_desc.push_back(cd);
       }
       sd.chunk_end = (int32_t)pl.chunk_desc.size();
-      if (sd.chunk_end - sd.chunk_begin > kSchurSuperChunks)
-        return "internal: super-run exceeds kSchurSuperChunks chunks";
+      if (sd.chunk_end - sd.chunk_begin > kSchurSuperChunks) {
+        run_error = "internal: super-run exceeds kSchurSuperChunks chunks";
+        return;
+      }
+      if (sd.chunk_end == sd.chunk_begin) {  // nothing to do after all: drop the run's slots
+        for (int s2 = 0; s2 < ns; ++s2) {
+          contrib.pop_back();
+          pl.slot_blk.pop_back();
+        }
+        for (int32_t bk : sup_blocks) mark[bk] = -1;
+        continue;
+      }
       pl.sup_desc.push_back(sd);
       deal_lanes(tcount, pl.sup_lane);
       if (getenv("BA_PLAN_STATS")) {  // balance of the triple loop (developer knob)
@@ -689,13 +731,13 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         for (int q = 0; q < 256; ++q)
           if ((lw[q] & 0xffu) < (uint32_t)ns) tps2[lw[q] & 0xffu] = (lw[q] >> 14) & 0x3f;
         for (int c = sd.chunk_begin; c < sd.chunk_end; ++c) {
-          const uint16_t *sp = &pl.chunk_sp[pl.chunk_desc[c].sp];
+          const uint16_t *sp2 = &pl.chunk_sp[pl.chunk_desc[c].sp];
           int mx = 0, tot = 0, act = 0;
           for (int q = 0; q < ns; ++q) {
-            const int cnt = sp[q + 1] - sp[q];
-            tot += cnt;
-            act += cnt > 0;
-            mx = std::max(mx, (cnt + tps2[q] - 1) / tps2[q]);
+            const int cnt2 = sp2[q + 1] - sp2[q];
+            tot += cnt2;
+            act += cnt2 > 0;
+            mx = std::max(mx, (cnt2 + tps2[q] - 1) / tps2[q]);
           }
           sum_max += mx;
           sum_ideal += tot * 2.0 / 256.0;
@@ -704,6 +746,28 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         }
       }
       for (int32_t bk : sup_blocks) mark[bk] = -1;
+    }
+    };
+    {
+      int i = pl.M_grp;
+      while (i < M && run_error.empty()) {
+        const int kd = kind_of(i);
+        if (kd == 2) {  // handled by the global triple list
+          ++i;
+          continue;
+        }
+        int j = i + 1;
+        while (j < M && kind_of(j) == kd && (kd == 0 || ngrp(j) == ngrp(i))) ++j;
+        if (kd == 0) {
+          build_runs(i, j, 0, 0, 0);
+        } else {
+          const int g = ngrp(i);
+          for (int ca = 0; ca < g; ++ca)
+            for (int cb = ca; cb < g; ++cb) build_runs(i, j, kSplit, ca, cb);
+        }
+        i = j;
+      }
+      if (!run_error.empty()) return run_error;
     }
     if (n_ch > 0)
       fprintf(stderr, "[plan] chunks %ld: triple-loop iterations per chunk: busiest lane %.2f, ideal %.2f; "

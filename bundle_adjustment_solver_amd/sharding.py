@@ -72,7 +72,11 @@ class TorchExchange:
         ptr = int(ptr or 0)
         st = self._streams.get(ptr)
         if st is None:
-            st = self.torch.cuda.ExternalStream(ptr, device=self.device)
+            # 0 is HIP's NULL stream = torch's default stream; ExternalStream(0)
+            # is NOT that stream on this PyTorch-ROCm build (observed: the collective
+            # then overtakes the kernels enqueued on NULL)
+            st = (self.torch.cuda.default_stream(self.device) if ptr == 0 else
+                  self.torch.cuda.ExternalStream(ptr, device=self.device))
             self._streams[ptr] = st
         return st
 

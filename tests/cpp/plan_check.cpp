@@ -72,7 +72,9 @@ int main(int argc, char **argv) {
   }
   // ---- Schur super-runs ----
   CHECK(pl.sup_lane.size() == pl.sup_desc.size() * 256, "lane table size");
-  std::vector<int> covered(pl.M, 0);
+  std::vector<int> covered(pl.M, 0);           // 1: all of the landmark's triples are in runs / groups
+  std::vector<int64_t> run_triples(pl.M, 0);   // triples of the landmark filed in super-run chunks
+  std::set<std::pair<int64_t, int64_t>> filed; // (pair p, pair q): every triple at most once
   int64_t triples = 0;
   for (size_t r = 0; r < pl.sup_desc.size(); ++r) {
     const auto &sd = pl.sup_desc[r];
@@ -105,7 +107,6 @@ int main(int argc, char **argv) {
                 cd.nt >= 1 && cd.nt <= ba::kSchurTri, "chunk limits");
       CHECK((cd.tb & 3) == 0 && cd.tb + cd.nt + 3 < (int64_t)pl.ltri.size(), "16-byte triple loads stay inside");
       CHECK(cd.p0 == pl.lm_pair_ptr[cd.l0], "chunk pair base");
-      for (int l = cd.l0; l < cd.l0 + cd.nl; ++l) covered[l]++;
       const uint16_t *sp = &pl.chunk_sp[cd.sp];
       CHECK(sp[0] == 0 && sp[sd.ns] == cd.nt, "slot offsets span the chunk's triples");
       for (int s = 0; s < sd.ns; ++s) {
@@ -115,6 +116,8 @@ int main(int argc, char **argv) {
           const int p = w >> 16, q = w & 0xff, lm = (w >> 8) & 0xff;
           CHECK(p < cd.np && q < cd.np && p <= q && lm < cd.nl, "triple word fields");
           CHECK(pl.pair_lm[cd.p0 + p] == cd.l0 + lm && pl.pair_lm[cd.p0 + q] == cd.l0 + lm, "triple's landmark");
+          CHECK(filed.insert({cd.p0 + p, cd.p0 + q}).second, "triple filed twice");
+          run_triples[cd.l0 + lm]++;
           const int jb = pl.pair_pose[cd.p0 + p], kb = pl.pair_pose[cd.p0 + q];
           const int blk = pl.slot_blk[sd.s0 + s];
           CHECK(pl.sblk_j[blk] == std::min(jb, kb) && pl.sblk_k[blk] == std::max(jb, kb), "triple filed under the wrong block");
@@ -122,6 +125,14 @@ int main(int argc, char **argv) {
       }
       triples += cd.nt;
     }
+  }
+  // a landmark is in the runs with ALL its triples (whole, or split into pose-group
+  // classes over several runs) or with none
+  for (int l = 0; l < pl.M; ++l) {
+    const int64_t d = pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l];
+    CHECK(run_triples[l] == 0 || run_triples[l] == d * (d + 1) / 2, "landmark %d: %lld of %lld triples in runs", l,
+          (long long)run_triples[l], (long long)(d * (d + 1) / 2));
+    covered[l] = run_triples[l] > 0;
   }
   // ---- covisibility groups: the first M_grp landmarks, group after group ----
   int64_t grp_triples = 0;

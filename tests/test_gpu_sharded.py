@@ -248,7 +248,7 @@ def test_two_shard_lm_loop_in_one_process(built):
     assert owned.all()
 
 
-def _rank_worker(rank, world, port, q):
+def _rank_worker(rank, world, port, q, null_stream=False):
     """Child process of test_two_rank_lm_loop_in_child_processes."""
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -264,7 +264,10 @@ def _rank_worker(rank, world, port, q):
         try:
             sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=23, pixel_sigma=0.3)
             pr = scenes.scaled_problem(sc)
-            p = make(pr, rank, world)
+            # null_stream: the handle runs on HIP's NULL stream (= torch's default
+            # stream, what torch.cuda.current_stream().cuda_stream reports), the
+            # other way a caller can drive the library
+            p = make(pr, rank, world, stream=0 if null_stream else None)
             ex = TorchExchange(p, dist, torch.device("cuda", 0), stage_host=True)
             rows, _ = p.solve(make_options(max_iter=12, thr_step=0, thr_cost=0))
             X, m = p.get_points()
@@ -278,12 +281,16 @@ def _rank_worker(rank, world, port, q):
         q.put((rank, "FAIL: " + traceback.format_exc(), None, None, None, None))
 
 
-def test_two_rank_lm_loop_in_child_processes(built):
+@pytest.mark.parametrize("null_stream", [False, True])
+def test_two_rank_lm_loop_in_child_processes(null_stream, built):
     """bench.py's N > 1 code path as an asserted test: two fresh processes (one
     rank each) share the card, landmarks sharded by ba_set_shard, the exchange
     through torch.distributed (gloo, staged through the host: the one-GPU box has
     no second device for RCCL) and sharding.TorchExchange.  Both ranks must
-    reproduce the one-rank trajectory to 1e-11 and end with identical poses."""
+    reproduce the one-rank trajectory to 1e-11 and end with identical poses.  Both
+    ways of giving the library a stream: its own (default) and HIP's NULL stream —
+    torch.cuda.ExternalStream(0) is NOT the NULL stream on this build, a collective
+    issued under it overtakes the kernels (the exchange then sums stale buffers)."""
     import torch.multiprocessing as mp
     sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=23, pixel_sigma=0.3)
     pr = scenes.scaled_problem(sc)
@@ -293,8 +300,8 @@ def test_two_rank_lm_loop_in_child_processes(built):
     full.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + (os.getpid() % 2000) + (1 if null_stream else 0)
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q, null_stream)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])

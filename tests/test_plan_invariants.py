@@ -34,6 +34,9 @@ def plan_check(tmp_path_factory):
     (["30", "400", "5", "2"], {"BA_SUP_CAP": "7", "BA_NO_GROUPS": "1"}),         # tiny runs
     (["200", "6000", "3", "3"], {"BA_SUP_CAP": "1000", "BA_NO_GROUPS": "1"}),    # runs ended by the slot / chunk limits
     (["200", "6000", "3", "3"], {}),                        # groups beside super-runs (groups below 24 stay in runs)
+    (["60", "3000", "20", "1"], {}),                        # windows of 20 poses: landmarks split into pose-group classes
+    (["60", "3000", "20", "1"], {"BA_NO_SPLIT": "1"}),      # the same on the global triple list
+    (["90", "2000", "37", "2"], {"BA_NO_GROUPS": "1"}),     # four pose groups per landmark, ten classes
 ])
 def test_plan_invariants(plan_check, args, env):
     r = subprocess.run([plan_check] + args, env=dict(os.environ, **env),
