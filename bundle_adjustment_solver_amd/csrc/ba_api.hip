@@ -159,8 +159,8 @@ void join_side(ba_handle *h) {
 // lcur ^ sel, cost partials as a by-product).
 void enqueue_linearize(ba_handle *h, int sel) {
   const ba::DevProblem &d = h->d;
+  ba::launch_lin_landmarks(d, sel, h->stream);  // (k_lin_grp's pose-side rows precede k_pose_finalize)
   ba::launch_lin_poses(d, sel, h->stream);
-  ba::launch_lin_landmarks(d, sel, h->stream);
   if (d.n_obs_lm < d.n_obs) ba::launch_cost(d, sel ? 2 : 0, d.n_obs_lm, h->stream);
 }
 
@@ -204,7 +204,10 @@ int enqueue_iteration(ba_handle *h) {
     // tiles: first needed by the NEXT iteration's k_schur_final.  BA_POSE_LATE=1
     // (default) starts them after k_lin_landmarks, beside the control step, the
     // damping kernel and the first part of k_schur_lds; 0 beside k_lin_landmarks.
-    static const bool late = !(getenv("BA_POSE_LATE") && getenv("BA_POSE_LATE")[0] == '0');
+    // (with covisibility groups linearised by k_lin_grp the pose-side sums of the
+    //  side stream's k_pose_finalize read that kernel's rows: always "late")
+    static const bool late_env = !(getenv("BA_POSE_LATE") && getenv("BA_POSE_LATE")[0] == '0');
+    const bool late = late_env || d.lin_chunk0 > 0;
     if (late) {
       ba::launch_lin_landmarks(d, 1, s);
       if (d.n_obs_lm < d.n_obs) ba::launch_cost(d, 2, d.n_obs_lm, s);
@@ -536,7 +539,7 @@ int ba_finalize(ba_handle *h) {
   }
   if (h->dalloc(&d.spart2, (size_t)d.n_slot * ba::kSlotStride)) return -1;
   {
-    static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 64,
+    static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 96,
                   "group descriptor layout");
     d.n_grp32 = (int)pl.grp32.size();
     d.n_grp64 = (int)pl.grp64.size();
@@ -545,6 +548,15 @@ int ba_finalize(ba_handle *h) {
       HIP_TRY(hipMemcpy(d.grp32, pl.grp32.data(), pl.grp32.size() * sizeof(ba::Plan::GrpDesc), hipMemcpyHostToDevice));
     if (d.n_grp64)
       HIP_TRY(hipMemcpy(d.grp64, pl.grp64.data(), pl.grp64.size() * sizeof(ba::Plan::GrpDesc), hipMemcpyHostToDevice));
+    // k_lin_grp: observation patterns, pose-side partial sums of the group pieces
+    d.lin_chunk0 = pl.lin_groups ? pl.n_bchunk_grp : 0;
+    d.n_lin_cost = d.n_bchunk + d.n_grp32 + d.n_grp64;
+    if (h->dalloc(&d.grp_pat, pl.grp_pat.size() / 2) || h->dalloc(&d.Apart2, (size_t)pl.n_apart2 * 27) ||
+        h->upload(&d.pose_gpart_ptr, pl.pose_gpart_ptr) || h->upload(&d.pose_gpart, pl.pose_gpart))
+      return -1;
+    if (!pl.grp_pat.empty())
+      HIP_TRY(hipMemcpy(d.grp_pat, pl.grp_pat.data(), pl.grp_pat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (pl.n_apart2 > 0) HIP_TRY(hipMemset(d.Apart2, 0, (size_t)pl.n_apart2 * 27 * sizeof(double)));
   }
 
   // per-iteration storage
@@ -559,14 +571,14 @@ int ba_finalize(ba_handle *h) {
   }
   d.n_obs_lm = pl.M > 0 ? pl.lm_obs_ptr[pl.M] : 0;
   if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.Cinv, (size_t)pl.M * 6) ||
-      h->dalloc(&d.lin_cost_part, (size_t)std::max(1, d.n_bchunk)) ||
+      h->dalloc(&d.lin_cost_part, (size_t)std::max(1, d.n_lin_cost)) ||
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) ||
       h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
       h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
       h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_bchunk) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
       h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
     return -1;
-  HIP_TRY(hipMemset(d.lin_cost_part, 0, (size_t)std::max(1, d.n_bchunk) * sizeof(double)));
+  HIP_TRY(hipMemset(d.lin_cost_part, 0, (size_t)std::max(1, d.n_lin_cost) * sizeof(double)));
   HIP_TRY(hipMemset(d.x, 0, ((size_t)pl.N * 6 + 64) * sizeof(double)));
   HIP_TRY(hipMemset(d.y, 0, std::max<size_t>(1, (size_t)pl.M * 3) * sizeof(double)));
   HIP_TRY(hipMemset(d.cost_part, 0, ba::kCostGrid * sizeof(double)));
@@ -1102,7 +1114,7 @@ const char *ba_kernel_name(int id) {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
       "k_schur_lds", "k_schur_partial", "k_schur_final", "k_scatter",
       "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_chol_diag_trsm", "k_chol_tail", "k_backsub_update",
-      "k_pose_update", "k_scalars", "k_control", "k_damp_invert", "k_schur_grp"};
+      "k_pose_update", "k_scalars", "k_control", "k_damp_invert", "k_schur_grp", "k_lin_grp"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
 }
 

@@ -98,9 +98,20 @@ struct DevProblem {
     int64_t p0;
     int32_t l0, nl, d, s0;
     int32_t pose[10];
+    int64_t o0;                // first observation: obs(il, oo) = o0 + no * il + oo
+    int32_t no, pat0;          // observations per landmark, first pattern entry in grp_pat
+    int32_t apart0, cost_idx;  // first of its d rows of Apart2, its entry of lin_cost_part
+    int32_t pad_[2];
   };
   GrpDesc *grp32, *grp64;  // pose sets of <= 5 / 6..10 poses
   int n_grp32, n_grp64;
+  // k_lin_grp (groups linearised landmark and pose side in one pass): per pattern
+  // slot {pose, camera | jj << 16 | optimisable << 29 | last writer << 30}
+  int2 *grp_pat;
+  double *Apart2;            // n_apart2 * 27 pose-side partial sums of the group pieces
+  int32_t *pose_gpart_ptr, *pose_gpart;  // rows of Apart2 per pose
+  int lin_chunk0;            // k_lin_landmarks starts at this chunk (the chunks before are k_lin_grp's)
+  int n_lin_cost;            // entries of lin_cost_part: n_bchunk + group pieces
   SupDesc *sup_desc;
   uint32_t *sup_lane;  // n_sup*256: lane -> (slot, half, position, lanes per half) of k_schur_lds
   ChunkDesc *chunk_desc;
@@ -175,7 +186,7 @@ enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
   K_SCHUR_LDS, K_SCHUR_PARTIAL, K_SCHUR_FINAL, K_SCATTER,
   K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_CHOL_DIAG_TRSM, K_CHOL_TAIL, K_BACKSUB_UPDATE,
-  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_DAMP_INVERT, K_SCHUR_GRP, K_COUNT
+  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_DAMP_INVERT, K_SCHUR_GRP, K_LIN_GRP, K_COUNT
 };
 struct KernelTimer {
   bool on = false;

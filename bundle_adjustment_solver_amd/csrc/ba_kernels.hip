@@ -460,7 +460,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d, int s
   __shared__ double smc[4];
   // dependent-load chain: chunk record (+ control word) -> observation records
   // (+ this thread's landmark range) -> pose / point gathers
-  const DevProblem::LmChunk lc = d.lm_chunk[blockIdx.x];
+  // (the chunks before lin_chunk0 hold the covisibility groups: k_lin_grp's)
+  const int chunk = blockIdx.x + d.lin_chunk0;
+  const DevProblem::LmChunk lc = d.lm_chunk[chunk];
   const int done = d.ctrl->done;
   const int buf = sel ? d.ctrl->tcur : d.ctrl->cur;
   const int lb = sel ? d.ctrl->tlcur : d.ctrl->lcur;
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d, int s
   // cost partial of this workgroup (k_scalars adds them in block order)
   {
     const double tot = block_sum(cost_acc, smc);
-    if (tid == 0) d.lin_cost_part[blockIdx.x] = tot;
+    if (tid == 0) d.lin_cost_part[chunk] = tot;
   }
   if (!own) return;
   // undamped C_i (upper) and b_i; damping and the inverse follow the control step
@@ -626,6 +628,204 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d, int s
   bo[0] = b0;
   bo[1] = b1;
   bo[2] = b2;
+}
+
+// --------------------------------------------------------------------------
+// Linearisation of the covisibility groups, landmark AND pose side in one pass
+// (reference :716-856).  The landmarks of a group share one observation pattern
+// (ba_plan.cpp): observation oo of every landmark is made by the same pose
+// through the same camera.  One workgroup per group piece, its four waves
+// independent; a wave step covers nlw = 64 / no consecutive landmarks, lane =
+// (landmark, pattern slot).  Pose and camera are LANE CONSTANTS (registers for
+// the whole kernel), the observation stream is read contiguously, the point is a
+// broadcast load: no index records, no gathers.  Per step:
+//   residual, weight, G, R, Q;  C_i / b_i terms through a wave-private LDS
+//   transposition to one lane per (landmark, value) that adds them in insertion
+//   order;  the compact cross block {K, X_ij} from the pair's last writer;
+//   A_j / a_j terms (21 + 6) into per-lane register accumulators.
+// At the end the accumulators are summed per pose of the group (over waves,
+// landmarks of a step and the pattern slots of that pose, fixed order) into one
+// row of Apart2 per (group piece, pose); k_pose_finalize adds the rows of a pose.
+// --------------------------------------------------------------------------
+template <bool LDSCAM>
+__global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
+  __shared__ double red[4 * 27 * 64];  // per wave: step transposition [64][9]; at the end [27][64]
+  __shared__ double cams_s[kCamLds * 16];
+  __shared__ double smc[4];
+  __shared__ int slot_b[10 + 1];  // first pattern slot of pose jj of the group (<= kGrpMaxPoses poses)
+  const int bid = blockIdx.x;
+  const DevProblem::GrpDesc *gp = bid < d.n_grp32 ? d.grp32 + bid : d.grp64 + (bid - d.n_grp32);
+  const int64_t p0 = gp->p0, o0 = gp->o0;
+  const int l0 = gp->l0, nl = gp->nl, dd = gp->d, no = gp->no, pat0 = gp->pat0;
+  const int apart0 = gp->apart0, cost_idx = gp->cost_idx;
+  const int done = d.ctrl->done;
+  const int buf = sel ? d.ctrl->tcur : d.ctrl->cur;
+  const int lb = sel ? d.ctrl->tlcur : d.ctrl->lcur;
+  const double huber = d.ctrl->huber;
+  if (LDSCAM) stage_cams(d, cams_s);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nlw = 64 / no;  // landmarks per wave step
+  const int ilw = lane / no, oo = lane - ilw * no;
+  const bool lane_on = ilw < nlw;
+  const int2 pat = d.grp_pat[pat0 + oo];
+  if (done) return;
+  const int cam_id = pat.y & 0xffff, jj = (pat.y >> 16) & 0xff;
+  const bool opt = (pat.y >> 29) & 1, lastw = (pat.y >> 30) & 1;
+  if (tid <= dd) {  // first slot of each optimisable pose (slots of a pose are adjacent)
+    int sb = no;
+    for (int q = no - 1; q >= 0; --q) {
+      const int2 pq = d.grp_pat[pat0 + q];
+      if (((pq.y >> 29) & 1) && ((pq.y >> 16) & 0xff) >= tid) sb = q;
+    }
+    // slots of fixed poses between two optimisable ones belong to nobody: the end of
+    // pose jj's range is found by its own scan below
+    slot_b[tid] = sb;
+  }
+  const double *__restrict__ pts = d.pts[buf];
+  double T[12], cam[16];
+  {
+    const double *Tp = d.poses[buf] + (size_t)pat.x * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = Tp[k];
+  }
+  __syncthreads();  // cams_s, slot_b
+  load_cam<LDSCAM>(d, cams_s, cam_id, cam);
+  double *__restrict__ Wg = d.W[lb];
+  double *__restrict__ Cg = d.Cu[lb];
+  double *__restrict__ bg = d.b[lb];
+  double *cbw = red + wv * (27 * 64);
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  double cost_acc = 0.0;
+  const int per_step = 4 * nlw;
+  const int nstep = (nl + per_step - 1) / per_step;
+  // the observation stream and the points of the next two steps are in flight
+  // while a step is processed (clamped indices: no conditional loads)
+  auto il_of = [&](int st) { return (st * 4 + wv) * nlw + ilw; };
+  auto clampi = [&](int il) { return il < nl ? il : nl - 1; };
+  double2 uvq[3];
+  double Xq[3][3];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ilc = clampi(il_of(u));
+    uvq[u] = d.obs_uv[o0 + (int64_t)ilc * no + oo];
+    const double *Xp = pts + (size_t)(l0 + ilc) * 3;
+    Xq[u][0] = Xp[0];
+    Xq[u][1] = Xp[1];
+    Xq[u][2] = Xp[2];
+  }
+  const int nsum = nlw * 9;  // (landmark, value) sums of a wave step
+#define LING_STEP(CUR, NXT2)                                                        \
+  {                                                                                 \
+    {                                                                               \
+      const int ilc_ = clampi(il_of(st + 2));                                       \
+      uvq[NXT2] = d.obs_uv[o0 + (int64_t)ilc_ * no + oo];                           \
+      const double *Xp_ = pts + (size_t)(l0 + ilc_) * 3;                            \
+      Xq[NXT2][0] = Xp_[0];                                                         \
+      Xq[NXT2][1] = Xp_[1];                                                         \
+      Xq[NXT2][2] = Xp_[2];                                                         \
+    }                                                                               \
+    const int il0_ = (st * 4 + wv) * nlw;                                           \
+    const int il_ = il0_ + ilw;                                                     \
+    const bool valid_ = lane_on && il_ < nl;                                        \
+    ObsGeom g;                                                                      \
+    project(cam, T, Xq[CUR][0], Xq[CUR][1], Xq[CUR][2], uvq[CUR].x, uvq[CUR].y, g); \
+    cost_acc += valid_ ? sqrt(g.r0 * g.r0 + g.r1 * g.r1) : 0.0;                     \
+    double w, G[6], Rm[6], Q[12];                                                   \
+    weight_and_G(cam, g, huber, w, G);                                              \
+    w = valid_ ? w : 0.0;                                                           \
+    make_R(G, T, Rm);                                                               \
+    const double wr0 = w * g.r0, wr1 = w * g.r1;                                    \
+    {                                                                               \
+      double *cb = cbw + lane * 9;                                                  \
+      cb[0] = w * (Rm[0] * Rm[0] + Rm[3] * Rm[3]);                                  \
+      cb[1] = w * (Rm[0] * Rm[1] + Rm[3] * Rm[4]);                                  \
+      cb[2] = w * (Rm[0] * Rm[2] + Rm[3] * Rm[5]);                                  \
+      cb[3] = w * (Rm[1] * Rm[1] + Rm[4] * Rm[4]);                                  \
+      cb[4] = w * (Rm[1] * Rm[2] + Rm[4] * Rm[5]);                                  \
+      cb[5] = w * (Rm[2] * Rm[2] + Rm[5] * Rm[5]);                                  \
+      cb[6] = Rm[0] * wr0 + Rm[3] * wr1;                                            \
+      cb[7] = Rm[1] * wr0 + Rm[4] * wr1;                                            \
+      cb[8] = Rm[2] * wr0 + Rm[5] * wr1;                                            \
+    }                                                                               \
+    if (valid_ && lastw) {                                                          \
+      /* B_ji = w Q^T R of the pair's last-inserted observation (reference :826), */ \
+      /* compact: K = w G^T R and X_ij (ba_device.h kWStride)                     */ \
+      double2 *Wp = (double2 *)(Wg + (size_t)(p0 + (int64_t)il_ * dd + jj) * kWStride); \
+      double kk[12];                                                                \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r)                                 \
+      _Pragma("unroll") for (int c = 0; c < 3; ++c)                                 \
+        kk[r * 3 + c] = w * (G[r] * Rm[c] + G[3 + r] * Rm[3 + c]);                  \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r) kk[9 + r] = g.Xij[r];           \
+      _Pragma("unroll") for (int r = 0; r < 6; ++r) Wp[r] = make_double2(kk[2 * r], kk[2 * r + 1]); \
+    }                                                                               \
+    {                                                                               \
+      /* pose side (reference :519-556, :809); fixed poses accumulate zeros */       \
+      const double wq = opt ? w : 0.0;                                              \
+      make_Q(G, g.Xij, Q);                                                          \
+      int k = 0;                                                                    \
+      _Pragma("unroll") for (int r = 0; r < 6; ++r) {                               \
+        const double q0 = wq * Q[r], q1 = wq * Q[6 + r];                            \
+        _Pragma("unroll") for (int c = r; c < 6; ++c)                               \
+          { acc[k] = fma(q0, Q[c], fma(q1, Q[6 + c], acc[k])); ++k; }               \
+      }                                                                             \
+      const double ar0 = wq * g.r0, ar1 = wq * g.r1;                                \
+      _Pragma("unroll") for (int c = 0; c < 6; ++c)                                 \
+        acc[21 + c] = fma(Q[c], ar0, fma(Q[6 + c], ar1, acc[21 + c]));              \
+    }                                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                          \
+    __builtin_amdgcn_wave_barrier();                                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
+    /* per-landmark sums in insertion order, one lane per (landmark, value) */      \
+    for (int t_ = lane; t_ < nsum; t_ += 64) {                                      \
+      const int li_ = t_ / 9, v_ = t_ - li_ * 9;                                    \
+      const double *cp_ = cbw + (li_ * no) * 9 + v_;                                \
+      double sacc_ = 0.0;                                                           \
+      for (int q_ = 0; q_ < no; ++q_) sacc_ += cp_[q_ * 9];                         \
+      const int ils_ = il0_ + li_;                                                  \
+      if (ils_ < nl) {                                                              \
+        if (v_ < 6) Cg[(size_t)(l0 + ils_) * 6 + v_] = sacc_;                       \
+        else bg[(size_t)(l0 + ils_) * 3 + (v_ - 6)] = -sacc_;                       \
+      }                                                                             \
+    }                                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                          \
+    __builtin_amdgcn_wave_barrier();                                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
+  }
+  int st = 0;
+  while (st < nstep) {
+    LING_STEP(0, 2)
+    if (++st >= nstep) break;
+    LING_STEP(1, 0)
+    if (++st >= nstep) break;
+    LING_STEP(2, 1)
+    ++st;
+  }
+#undef LING_STEP
+  // pose-side partial sums of this piece: registers -> LDS [wave][value][lane] ->
+  // one thread per (pose of the group, value)
+#pragma unroll
+  for (int k = 0; k < 27; ++k) cbw[k * 64 + lane] = acc[k];
+  {
+    const double tot = block_sum(cost_acc, smc);  // (contains the barrier that publishes red[])
+    if (tid == 0) d.lin_cost_part[cost_idx] = tot;
+  }
+  __syncthreads();
+  for (int t = tid; t < dd * 27; t += kBlock) {
+    const int pj = t / 27, e = t - pj * 27;
+    const int sb = slot_b[pj];
+    int se = sb;  // its slots: adjacent pattern entries with the same pose
+    {
+      const int pose_j = d.grp_pat[pat0 + sb].x;
+      while (se < no && d.grp_pat[pat0 + se].x == pose_j) ++se;
+    }
+    double sacc = 0.0;
+    for (int w4 = 0; w4 < 4; ++w4)
+      for (int li = 0; li < nlw; ++li)
+        for (int q = sb; q < se; ++q) sacc += red[(w4 * 27 + e) * 64 + li * no + q];
+    d.Apart2[(size_t)(apart0 + pj) * 27 + e] = sacc;
+  }
 }
 
 // Damping and landmark inverse (reference :846-856): Cinv_i = (C_i with its
@@ -776,6 +976,9 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d, int sel)
   double s = 0.0;
   for (int ch = d.pose_achunk_ptr[j]; ch < d.pose_achunk_ptr[j + 1]; ++ch)
     s += d.Apart[(size_t)ch * 27 + e];
+  // rows of the covisibility-group pieces that see this pose (k_lin_grp)
+  for (int q = d.pose_gpart_ptr[j]; q < d.pose_gpart_ptr[j + 1]; ++q)
+    s += d.Apart2[(size_t)d.pose_gpart[q] * 27 + e];
   if (e < 21) {
     // upper-triangle index -> (r, c)
     int r = 0, k = e;
@@ -1810,12 +2013,12 @@ __global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode, 
   }
   if (cost_src == 1) {  // eight independent loads in flight per thread
     const double *lp = d.lin_cost_part;
-    for (int k0 = threadIdx.x; k0 < d.n_bchunk; k0 += 8 * kScalBlock) {
+    for (int k0 = threadIdx.x; k0 < d.n_lin_cost; k0 += 8 * kScalBlock) {
       double v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int k = k0 + u * kScalBlock;
-        v[u] = k < d.n_bchunk ? lp[k] : 0.0;
+        v[u] = k < d.n_lin_cost ? lp[k] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) c += v[u];
@@ -1982,11 +2185,19 @@ void launch_cost(const DevProblem &d, int sel, int64_t begin, hipStream_t s) {
 }
 
 void launch_lin_landmarks(const DevProblem &d, int sel, hipStream_t s) {
-  if (d.n_bchunk <= 0) return;
+  if (d.lin_chunk0 > 0) {  // covisibility groups: landmark and pose side in one pass
+    const int ng = d.n_grp32 + d.n_grp64;
+    if (d.n_cam <= kCamLds)
+      BA_LAUNCH(K_LIN_GRP, k_lin_grp<true>, dim3(ng), dim3(kBlock), s, d, sel);
+    else
+      BA_LAUNCH(K_LIN_GRP, k_lin_grp<false>, dim3(ng), dim3(kBlock), s, d, sel);
+  }
+  const int nch = d.n_bchunk - d.lin_chunk0;
+  if (nch <= 0) return;
   if (d.n_cam <= kCamLds)
-    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<true>, dim3(d.n_bchunk), dim3(kBlock), s, d, sel);
+    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<true>, dim3(nch), dim3(kBlock), s, d, sel);
   else
-    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<false>, dim3(d.n_bchunk), dim3(kBlock), s, d, sel);
+    BA_LAUNCH(K_LIN_LANDMARKS, k_lin_landmarks<false>, dim3(nch), dim3(kBlock), s, d, sel);
 }
 
 void launch_lin_poses(const DevProblem &d, int sel, hipStream_t s) {

@@ -217,46 +217,65 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     }
   }
   pl.M = (int)pl.pt_user_of_int.size();
-  // ---- covisibility groups: landmarks with the identical set of optimisable
-  // poses (1..kGrpMaxPoses of them) in groups of >= kGrpMinLandmarks come FIRST,
-  // group after group (groups ordered by their pose lists, i.e. still by first
-  // observing pose; landmarks of a group in locality order); k_schur_grp turns
-  // each group into one dense product.  Everything else keeps the locality order
-  // and goes through the super-runs. ----
+  // ---- covisibility groups: landmarks with the identical OBSERVATION PATTERN —
+  // the same sequence of (pose, camera) over their observations in landmark-major
+  // order, fixed poses included — hence the identical set of optimisable poses
+  // (1..kGrpMaxPoses of them), in groups of >= kGrpMinLandmarks come FIRST, group
+  // after group (groups ordered by their patterns, i.e. still by first observing
+  // pose; landmarks of a group in locality order).  k_lin_grp linearises a group
+  // with one lane per pattern slot (pose and camera are lane constants: no
+  // gathers, no index records, pose side in the same pass); k_schur_grp turns its
+  // Schur contributions into one dense product.  Everything else keeps the
+  // locality order and goes through the chunk / super-run kernels. ----
   pl.M_grp = 0;
   pl.grp_range.clear();
+  pl.lin_groups = !(getenv("BA_NO_LINGRP") && getenv("BA_NO_LINGRP")[0] == '1');
   if (pl.M > 0 && !(getenv("BA_NO_GROUPS") && getenv("BA_NO_GROUPS")[0] == '1')) {
     const int M0 = pl.M;
-    std::vector<uint64_t> keys;
-    keys.reserve(in.n_obs / in.world + 16);
+    std::vector<int64_t> kp(M0 + 1, 0);
     for (int64_t k = 0; k < in.n_obs; ++k) {
       const int32_t pi = pl.pt_int_of_user[in.obs_pt[k]];
-      const int32_t ji = pl.pose_int_of_user[in.obs_pose[k]];
-      if (pi >= 0 && ji < N) keys.push_back(((uint64_t)(uint32_t)pi << 32) | (uint32_t)ji);
+      if (pi >= 0) kp[pi + 1]++;
     }
-    std::sort(keys.begin(), keys.end());
-    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-    std::vector<int64_t> kp(M0 + 1, 0);
-    for (uint64_t key : keys) kp[(key >> 32) + 1]++;
     for (int i = 0; i < M0; ++i) kp[i + 1] += kp[i];
-    auto deg = [&](int i) { return (int)(kp[i + 1] - kp[i]); };
-    auto less_sig = [&](int a, int b) {  // lexicographic on the pose lists, shorter first on ties
-      const int da = deg(a), db = deg(b);
-      for (int t = 0; t < std::min(da, db); ++t) {
-        const uint32_t pa = (uint32_t)keys[kp[a] + t], pb = (uint32_t)keys[kp[b] + t];
-        if (pa != pb) return pa < pb;
+    std::vector<uint64_t> pat((size_t)kp[M0]);  // (pose << 32) | camera, per point in (pose, insertion) order
+    {
+      std::vector<int64_t> cur(kp.begin(), kp.end() - 1);
+      for (int64_t k = 0; k < in.n_obs; ++k) {
+        const int32_t pi = pl.pt_int_of_user[in.obs_pt[k]];
+        if (pi >= 0)
+          pat[cur[pi]++] = ((uint64_t)(uint32_t)pl.pose_int_of_user[in.obs_pose[k]] << 32) | (uint32_t)in.obs_cam[k];
       }
+      for (int i = 0; i < M0; ++i)
+        std::stable_sort(pat.begin() + kp[i], pat.begin() + kp[i + 1],
+                         [](uint64_t x, uint64_t y) { return (x >> 32) < (y >> 32); });
+    }
+    auto deg = [&](int i) { return (int)(kp[i + 1] - kp[i]); };
+    auto dopt = [&](int i) {  // distinct optimisable poses
+      int n = 0;
+      int64_t last = -1;
+      for (int64_t t = kp[i]; t < kp[i + 1]; ++t) {
+        const int64_t ji = (int64_t)(pat[t] >> 32);
+        if (ji < N && ji != last) ++n;
+        last = ji;
+      }
+      return n;
+    };
+    auto less_sig = [&](int a, int b) {  // lexicographic on the patterns, shorter first on ties
+      const int da = deg(a), db = deg(b);
+      for (int t = 0; t < std::min(da, db); ++t)
+        if (pat[kp[a] + t] != pat[kp[b] + t]) return pat[kp[a] + t] < pat[kp[b] + t];
       return da < db;
     };
     auto same_sig = [&](int a, int b) {
-      if (deg(a) != deg(b)) return false;
-      for (int t = 0; t < deg(a); ++t)
-        if ((uint32_t)keys[kp[a] + t] != (uint32_t)keys[kp[b] + t]) return false;
-      return true;
+      return deg(a) == deg(b) && std::equal(pat.begin() + kp[a], pat.begin() + kp[a + 1], pat.begin() + kp[b]);
     };
     std::vector<int32_t> cand;
-    for (int i = 0; i < M0; ++i)
-      if (deg(i) >= 1 && deg(i) <= kGrpMaxPoses) cand.push_back(i);
+    std::vector<int32_t> dop(M0, 0);
+    for (int i = 0; i < M0; ++i) {
+      dop[i] = dopt(i);
+      if (dop[i] >= 1 && dop[i] <= kGrpMaxPoses && deg(i) <= kGrpMaxObs) cand.push_back(i);
+    }
     std::stable_sort(cand.begin(), cand.end(), less_sig);  // stable: locality order inside a group
     std::vector<uint8_t> grouped(M0, 0);
     std::vector<int32_t> neworder;
@@ -269,7 +288,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         Plan::GrpRange gr;
         gr.l0 = (int32_t)neworder.size();
         gr.nl = (int32_t)(b - a);
-        gr.d = deg(cand[a]);
+        gr.d = dop[cand[a]];
+        gr.no = deg(cand[a]);
         pl.grp_range.push_back(gr);
         for (size_t t = a; t < b; ++t) {
           grouped[cand[t]] = 1;
@@ -284,6 +304,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     pl.pt_user_of_int.swap(neworder);
     for (int k = 0; k < M0; ++k) pl.pt_int_of_user[pl.pt_user_of_int[k]] = k;
   }
+  if (pl.M_grp == 0) pl.lin_groups = false;
   // Interleave inside windows of one Schur super-run: position p of a window
   // takes the landmark p would have had in residue-class order (k = r, r + S,
   // r + 2S, ...), so that every chunk of consecutive landmarks samples the
@@ -378,8 +399,10 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   {
     std::vector<int64_t> psel;
     psel.reserve(pl.n_obs);
+    // (observations of landmarks in covisibility groups are linearised, pose side
+    //  included, by k_lin_grp: they do not enter the pose-major list)
     for (int64_t s = 0; s < pl.n_obs; ++s)
-      if (pl.obs_idx[4 * s + 1] < N) psel.push_back(s);
+      if (pl.obs_idx[4 * s + 1] < N && !(pl.lin_groups && pl.obs_idx[4 * s + 2] < pl.M_grp)) psel.push_back(s);
     // stable counting sort by pose keeps (point, insertion) order inside
     pl.pose_obs_ptr.assign(N + 1, 0);
     for (int64_t s : psel) pl.pose_obs_ptr[pl.obs_idx[4 * s + 1] + 1]++;
@@ -541,11 +564,31 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     // d (d + 1) / 2 slots each, in (jj, kk) row-major order of the upper triangle
     pl.grp32.clear();
     pl.grp64.clear();
+    pl.grp_pat.clear();
+    pl.n_apart2 = 0;
     for (const Plan::GrpRange &gr : pl.grp_range) {
       const int64_t p0 = pl.lm_pair_ptr[gr.l0];
       for (int l = gr.l0; l < gr.l0 + gr.nl; ++l)
-        if (pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l] != gr.d)
+        if (pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l] != gr.d ||
+            pl.lm_obs_ptr[l + 1] - pl.lm_obs_ptr[l] != gr.no)
           return "internal: covisibility group with a ragged landmark";
+      // observation pattern of the group, from its first landmark
+      const int32_t pat0 = (int32_t)(pl.grp_pat.size() / 2);
+      {
+        const int64_t ob = pl.lm_obs_ptr[gr.l0];
+        int jj = -1;
+        int32_t lastp = -1;
+        for (int oo = 0; oo < gr.no; ++oo) {
+          const int32_t ji = pl.obs_idx[4 * (ob + oo) + 1], cam = pl.obs_idx[4 * (ob + oo) + 0];
+          const bool opt = ji < N;
+          if (opt && ji != lastp) ++jj;
+          lastp = ji;
+          const bool lastw = pl.obs_idx[4 * (ob + oo) + 3] >= 0;
+          pl.grp_pat.push_back(ji);
+          pl.grp_pat.push_back(cam | ((opt ? jj : 0) << 16) | (opt ? 1 << 29 : 0) | (lastw ? 1 << 30 : 0));
+        }
+        if (jj + 1 != gr.d) return "internal: covisibility group pattern / pose count mismatch";
+      }
       static const int grp_max = getenv("BA_GRP_MAX") ? std::max(12, atoi(getenv("BA_GRP_MAX"))) : kGrpMaxLandmarks;
       const int pieces = (gr.nl + grp_max - 1) / grp_max;
       const int per = (gr.nl + pieces - 1) / pieces;
@@ -556,6 +599,13 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         gd.d = gr.d;
         gd.p0 = p0 + (int64_t)gr.d * c0;
         gd.s0 = (int32_t)pl.slot_blk.size();
+        gd.no = gr.no;
+        gd.o0 = pl.lm_obs_ptr[gd.l0];
+        gd.pat0 = pat0;
+        gd.apart0 = (int32_t)pl.n_apart2;
+        gd.cost_idx = 0;  // set below, after the chunks are known
+        gd.pad_[0] = gd.pad_[1] = 0;
+        pl.n_apart2 += gr.d;
         for (int t = 0; t < kGrpMaxPoses; ++t) gd.pose[t] = t < gr.d ? pl.pair_pose[p0 + t] : 0;
         for (int jj = 0; jj < gr.d; ++jj)
           for (int kk = jj; kk < gr.d; ++kk) {
@@ -789,19 +839,42 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   // ---- back-substitution chunks: consecutive landmarks, <= kSchurPairs pairs
   // (a landmark with more pairs forms a chunk of its own) ----
   {
+    // (a chunk does not straddle M_grp: with lin_groups k_lin_landmarks starts
+    //  at chunk n_bchunk_grp, the grouped landmarks are k_lin_grp's)
     pl.bchunk_lm.assign(1, 0);
+    pl.n_bchunk_grp = 0;
     int l = 0;
     while (l < M) {
       int64_t np = 0;
       const int c0 = l;
-      while (l < M && l - c0 < kSchurLandmarks) {
+      const int lim = l < pl.M_grp ? pl.M_grp : M;
+      while (l < lim && l - c0 < kSchurLandmarks) {
         const int64_t dd = pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l];
         if (l > c0 && np + dd > kSchurPairs) break;
         np += dd;
         ++l;
       }
       pl.bchunk_lm.push_back(l);
+      if (l <= pl.M_grp) pl.n_bchunk_grp = (int)pl.bchunk_lm.size() - 1;
     }
+  }
+  // ---- k_lin_grp bookkeeping: cost-partial entry of each group piece (after the
+  // chunks' entries), rows of Apart2 per pose ----
+  {
+    int32_t ci = (int32_t)pl.bchunk_lm.size() - 1;
+    for (auto &g : pl.grp32) g.cost_idx = ci++;
+    for (auto &g : pl.grp64) g.cost_idx = ci++;
+    pl.pose_gpart_ptr.assign(N + 1, 0);
+    if (!pl.lin_groups) pl.n_apart2 = 0;
+    for (auto *gv : {&pl.grp32, &pl.grp64})
+      for (auto &g : *gv)
+        for (int t = 0; pl.lin_groups && t < g.d; ++t) pl.pose_gpart_ptr[g.pose[t] + 1]++;
+    for (int j = 0; j < N; ++j) pl.pose_gpart_ptr[j + 1] += pl.pose_gpart_ptr[j];
+    pl.pose_gpart.assign((size_t)pl.pose_gpart_ptr[N], 0);
+    std::vector<int32_t> cur(pl.pose_gpart_ptr.begin(), pl.pose_gpart_ptr.end() - 1);
+    for (auto *gv : {&pl.grp32, &pl.grp64})
+      for (auto &g : *gv)
+        for (int t = 0; pl.lin_groups && t < g.d; ++t) pl.pose_gpart[cur[g.pose[t]]++] = g.apart0 + t;
   }
 
   return std::string();
