@@ -539,8 +539,10 @@ int ba_finalize(ba_handle *h) {
   }
   if (h->dalloc(&d.spart2, (size_t)d.n_slot * ba::kSlotStride)) return -1;
   {
-    static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 96,
+    static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 64,
                   "group descriptor layout");
+    static_assert(sizeof(ba::Plan::LinDesc) == sizeof(ba::DevProblem::LinDesc) && sizeof(ba::Plan::LinDesc) == 48,
+                  "group linearisation descriptor layout");
     d.n_grp32 = (int)pl.grp32.size();
     d.n_grp64 = (int)pl.grp64.size();
     if (h->dalloc(&d.grp32, pl.grp32.size()) || h->dalloc(&d.grp64, pl.grp64.size())) return -1;
@@ -550,8 +552,12 @@ int ba_finalize(ba_handle *h) {
       HIP_TRY(hipMemcpy(d.grp64, pl.grp64.data(), pl.grp64.size() * sizeof(ba::Plan::GrpDesc), hipMemcpyHostToDevice));
     // k_lin_grp: observation patterns, pose-side partial sums of the group pieces
     d.lin_chunk0 = pl.lin_groups ? pl.n_bchunk_grp : 0;
-    d.n_lin_cost = d.n_bchunk + d.n_grp32 + d.n_grp64;
-    if (h->dalloc(&d.grp_pat, pl.grp_pat.size() / 2) || h->dalloc(&d.Apart2, (size_t)pl.n_apart2 * 27) ||
+    d.n_lin_desc = (int)pl.lin_desc.size();
+    d.n_lin_cost = d.n_bchunk + d.n_lin_desc;
+    if (h->dalloc(&d.lin_desc, pl.lin_desc.size())) return -1;
+    if (d.n_lin_desc)
+      HIP_TRY(hipMemcpy(d.lin_desc, pl.lin_desc.data(), pl.lin_desc.size() * sizeof(ba::Plan::LinDesc), hipMemcpyHostToDevice));
+    if (h->dalloc(&d.grp_pat, pl.grp_pat.size() / 2) || h->dalloc(&d.Apart2, (size_t)pl.n_apart2 * 27) || h->dalloc(&d.lin_dump, (size_t)ba::kLinDump) ||
         h->upload(&d.pose_gpart_ptr, pl.pose_gpart_ptr) || h->upload(&d.pose_gpart, pl.pose_gpart))
       return -1;
     if (!pl.grp_pat.empty())

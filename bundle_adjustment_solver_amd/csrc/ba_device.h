@@ -98,20 +98,26 @@ struct DevProblem {
     int64_t p0;
     int32_t l0, nl, d, s0;
     int32_t pose[10];
-    int64_t o0;                // first observation: obs(il, oo) = o0 + no * il + oo
-    int32_t no, pat0;          // observations per landmark, first pattern entry in grp_pat
-    int32_t apart0, cost_idx;  // first of its d rows of Apart2, its entry of lin_cost_part
-    int32_t pad_[2];
   };
+  struct LinDesc {  // one k_lin_grp workgroup: layout-identical to Plan::LinDesc
+    int64_t p0, o0;
+    int32_t l0, nl, d, no;
+    int32_t pat0;
+    int32_t apart0, cost_idx;
+    int32_t pad_;
+  };
+  LinDesc *lin_desc;
+  int n_lin_desc;
   GrpDesc *grp32, *grp64;  // pose sets of <= 5 / 6..10 poses
   int n_grp32, n_grp64;
   // k_lin_grp (groups linearised landmark and pose side in one pass): per pattern
   // slot {pose, camera | jj << 16 | optimisable << 29 | last writer << 30}
   int2 *grp_pat;
   double *Apart2;            // n_apart2 * 27 pose-side partial sums of the group pieces
+  double *lin_dump;          // kLinDump doubles: target of k_lin_grp's lanes with nothing to store
   int32_t *pose_gpart_ptr, *pose_gpart;  // rows of Apart2 per pose
   int lin_chunk0;            // k_lin_landmarks starts at this chunk (the chunks before are k_lin_grp's)
-  int n_lin_cost;            // entries of lin_cost_part: n_bchunk + group pieces
+  int n_lin_cost;            // entries of lin_cost_part: n_bchunk + k_lin_grp pieces
   SupDesc *sup_desc;
   uint32_t *sup_lane;  // n_sup*256: lane -> (slot, half, position, lanes per half) of k_schur_lds
   ChunkDesc *chunk_desc;
@@ -173,6 +179,7 @@ struct DevProblem {
   int n_zt;
 };
 
+constexpr int kLinDump = 64 * 4 * 4;
 constexpr int kCostGrid = 1792;  // 7 waves/SIMD resident on 256 CUs
 constexpr int kLmGrid = 1024;
 constexpr int kPoseGrid = 16;

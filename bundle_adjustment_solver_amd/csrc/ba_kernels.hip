@@ -647,14 +647,28 @@ __global__ __launch_bounds__(kBlock, 5) void k_lin_landmarks(DevProblem d, int s
 // landmarks of a step and the pattern slots of that pose, fixed order) into one
 // row of Apart2 per (group piece, pose); k_pose_finalize adds the rows of a pose.
 // --------------------------------------------------------------------------
+#ifdef BA_LG_DBG
+__device__ long long g_lg_dbg[64];
+#define LG_STAMP() { if (lg_on && lg_n < 64) lg_s[lg_n++] = clock64(); }
+#else
+#define LG_STAMP()
+#endif
 template <bool LDSCAM>
 __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
-  __shared__ double red[4 * 27 * 64];  // per wave: step transposition [64][9]; at the end [27][64]
+#ifdef BA_LG_DBG
+  __shared__ long long lg_s[64];
+  const bool lg_on = blockIdx.x == 300 && threadIdx.x == 0;
+  int lg_n = 0;
+#endif
+  LG_STAMP()
+  // per wave: step transposition [64][9] + W image of the step; at the end [14][64]
+  constexpr int kLgArea = 64 * 9 + 7 * 10 * 12;
+  __shared__ __attribute__((aligned(16))) double red[4 * kLgArea];
   __shared__ double cams_s[kCamLds * 16];
   __shared__ double smc[4];
-  __shared__ int slot_b[10 + 1];  // first pattern slot of pose jj of the group (<= kGrpMaxPoses poses)
+  __shared__ int slot_b[10], slot_e[10];  // pattern slots of pose jj of the group (<= kGrpMaxPoses poses)
   const int bid = blockIdx.x;
-  const DevProblem::GrpDesc *gp = bid < d.n_grp32 ? d.grp32 + bid : d.grp64 + (bid - d.n_grp32);
+  const DevProblem::LinDesc *gp = d.lin_desc + bid;
   const int64_t p0 = gp->p0, o0 = gp->o0;
   const int l0 = gp->l0, nl = gp->nl, dd = gp->d, no = gp->no, pat0 = gp->pat0;
   const int apart0 = gp->apart0, cost_idx = gp->cost_idx;
@@ -664,22 +678,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
   const double huber = d.ctrl->huber;
   if (LDSCAM) stage_cams(d, cams_s);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int nlw = 64 / no;  // landmarks per wave step
+  // landmarks per wave step; at most 7, so that the 9 nlw (landmark, value) sums of a
+  // step are ONE lane each
+  const int nlw = 64 / no < 7 ? 64 / no : 7;
   const int ilw = lane / no, oo = lane - ilw * no;
   const bool lane_on = ilw < nlw;
   const int2 pat = d.grp_pat[pat0 + oo];
   if (done) return;
   const int cam_id = pat.y & 0xffff, jj = (pat.y >> 16) & 0xff;
   const bool opt = (pat.y >> 29) & 1, lastw = (pat.y >> 30) & 1;
-  if (tid <= dd) {  // first slot of each optimisable pose (slots of a pose are adjacent)
-    int sb = no;
-    for (int q = no - 1; q >= 0; --q) {
-      const int2 pq = d.grp_pat[pat0 + q];
-      if (((pq.y >> 29) & 1) && ((pq.y >> 16) & 0xff) >= tid) sb = q;
+  // pattern slots [slot_b, slot_e) of each optimisable pose (the slots of a pose are
+  // adjacent): found from the neighbours' pattern entries, no further loads
+  {
+    const int pose_prev = __shfl_up(pat.x, 1), pose_next = __shfl_down(pat.x, 1);
+    if (tid < no && opt) {
+      if (oo == 0 || pose_prev != pat.x) slot_b[jj] = oo;
+      if (oo == no - 1 || pose_next != pat.x) slot_e[jj] = oo + 1;
     }
-    // slots of fixed poses between two optimisable ones belong to nobody: the end of
-    // pose jj's range is found by its own scan below
-    slot_b[tid] = sb;
   }
   const double *__restrict__ pts = d.pts[buf];
   double T[12], cam[16];
@@ -693,7 +708,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
   double *__restrict__ Wg = d.W[lb];
   double *__restrict__ Cg = d.Cu[lb];
   double *__restrict__ bg = d.b[lb];
-  double *cbw = red + wv * (27 * 64);
+  double *cbw = red + wv * kLgArea;
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
   // the observation stream and the points of the next two steps are in flight
   // while a step is processed (clamped indices: no conditional loads)
   auto il_of = [&](int st) { return (st * 4 + wv) * nlw + ilw; };
-  auto clampi = [&](int il) { return il < nl ? il : nl - 1; };
+  auto clampi = [&](int il) { return min(il, nl - 1); };
   double2 uvq[3];
   double Xq[3][3];
 #pragma unroll
@@ -715,9 +730,59 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
     Xq[u][1] = Xp[1];
     Xq[u][2] = Xp[2];
   }
-  const int nsum = nlw * 9;  // (landmark, value) sums of a wave step
+  // this lane's (landmark, value) sum of a wave step and where it goes
+  const int sum_li = lane / 9, sum_v = lane - sum_li * 9;
+  const bool sum_on = lane < nlw * 9, sum_neg = sum_v >= 6;
+  const double *sum_p = cbw + (sum_on ? sum_li * no * 9 + sum_v : 0);
+  double *sum_g = sum_v < 6 ? Cg + (size_t)l0 * 6 + sum_v : bg + (size_t)l0 * 3 + (sum_v - 6);
+  const int sum_stride = sum_v < 6 ? 6 : 3;
+  // dump area of the lanes that have nothing to store (see LING_STEP)
+  double2 *dumpW = (double2 *)(d.lin_dump + (size_t)((bid & 63) * 4 + wv) * 4);
+  double *dumpC = (double *)dumpW + 2;
+  // LDS image of the W records of a wave step (behind the transposition area):
+  // nlw * d <= 7 * 10 records of 6 double2
+  double2 *stgW = (double2 *)(cbw + 64 * 9);
+  double2 *stgW_mine = stgW + (ilw * dd + jj) * 6;
+  constexpr int kLgPass = (7 * 10 * 6 + 63) / 64;
+  // A step is software-pipelined against the previous one: the step's terms go to
+  // the wave's LDS area at its END; the per-landmark sums and the W image of step
+  // st - 1 are READ from LDS at the start of step st (requests in flight during the
+  // arithmetic of step st) and stored to global after it.  il0p = first landmark of
+  // the step whose terms are in LDS (nl: none yet, everything goes to the dump).
+  int il0p = nl;
+  double vv[8];
+  double2 wvv[kLgPass];
+  int lastp = 0;
+  double2 *dstWp = dumpW;
+  // requests of the LDS reads for the step in LDS
+#define LING_FLUSH_ISSUE()                                                          \
+  {                                                                                 \
+    _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) vv[u_] = sum_p[(u_ < no ? u_ : 0) * 9]; \
+    const int nls_ = nl - il0p < nlw ? nl - il0p : nlw;                             \
+    const int n2_ = nls_ * dd * 6;                                                  \
+    dstWp = n2_ > 0 ? (double2 *)(Wg + (size_t)(p0 + (int64_t)il0p * dd) * kWStride) : dumpW; \
+    lastp = n2_ > 0 ? n2_ - 1 : 0;                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < kLgPass; ++k_) wvv[k_] = stgW[min(lane + 64 * k_, lastp)]; \
+  }
+  // per-landmark sums in insertion order (one lane per (landmark, value)) and the W
+  // image -> global.  A FIXED number of store instructions, none under a branch (a
+  // store under a branch makes the compiler's vmcnt bookkeeping wait for every load
+  // in flight): lanes with nothing to store write to a dump, W passes past the end
+  // repeat the last 16-byte piece (one request each).
+#define LING_FLUSH_FINISH()                                                         \
+  {                                                                                 \
+    double sacc_ = 0.0;                                                             \
+    _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) sacc_ += (u_ < no) ? vv[u_] : 0.0; \
+    for (int q_ = 8; q_ < no; ++q_) sacc_ += sum_p[q_ * 9];                         \
+    const int ils_ = il0p + sum_li;                                                 \
+    double *dst_ = (sum_on && ils_ < nl) ? sum_g + (size_t)ils_ * sum_stride : dumpC; \
+    *dst_ = sum_neg ? -sacc_ : sacc_;                                               \
+    _Pragma("unroll") for (int k_ = 0; k_ < kLgPass; ++k_) dstWp[min(lane + 64 * k_, lastp)] = wvv[k_]; \
+  }
 #define LING_STEP(CUR, NXT2)                                                        \
   {                                                                                 \
+    LG_STAMP()                                                                      \
+    LING_FLUSH_ISSUE()                                                              \
     {                                                                               \
       const int ilc_ = clampi(il_of(st + 2));                                       \
       uvq[NXT2] = d.obs_uv[o0 + (int64_t)ilc_ * no + oo];                           \
@@ -732,33 +797,29 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
     ObsGeom g;                                                                      \
     project(cam, T, Xq[CUR][0], Xq[CUR][1], Xq[CUR][2], uvq[CUR].x, uvq[CUR].y, g); \
     cost_acc += valid_ ? sqrt(g.r0 * g.r0 + g.r1 * g.r1) : 0.0;                     \
-    double w, G[6], Rm[6], Q[12];                                                   \
+    double w, G[6], Rm[6], Q[12], cbv[9], kk[12];                                   \
     weight_and_G(cam, g, huber, w, G);                                              \
     w = valid_ ? w : 0.0;                                                           \
     make_R(G, T, Rm);                                                               \
-    const double wr0 = w * g.r0, wr1 = w * g.r1;                                    \
     {                                                                               \
-      double *cb = cbw + lane * 9;                                                  \
-      cb[0] = w * (Rm[0] * Rm[0] + Rm[3] * Rm[3]);                                  \
-      cb[1] = w * (Rm[0] * Rm[1] + Rm[3] * Rm[4]);                                  \
-      cb[2] = w * (Rm[0] * Rm[2] + Rm[3] * Rm[5]);                                  \
-      cb[3] = w * (Rm[1] * Rm[1] + Rm[4] * Rm[4]);                                  \
-      cb[4] = w * (Rm[1] * Rm[2] + Rm[4] * Rm[5]);                                  \
-      cb[5] = w * (Rm[2] * Rm[2] + Rm[5] * Rm[5]);                                  \
-      cb[6] = Rm[0] * wr0 + Rm[3] * wr1;                                            \
-      cb[7] = Rm[1] * wr0 + Rm[4] * wr1;                                            \
-      cb[8] = Rm[2] * wr0 + Rm[5] * wr1;                                            \
-    }                                                                               \
-    if (valid_ && lastw) {                                                          \
+      /* landmark side (reference :503-517, :817-823) through w R */                \
+      double wR[6];                                                                 \
+      _Pragma("unroll") for (int e_ = 0; e_ < 6; ++e_) wR[e_] = w * Rm[e_];         \
+      cbv[0] = Rm[0] * wR[0] + Rm[3] * wR[3];                                       \
+      cbv[1] = Rm[0] * wR[1] + Rm[3] * wR[4];                                       \
+      cbv[2] = Rm[0] * wR[2] + Rm[3] * wR[5];                                       \
+      cbv[3] = Rm[1] * wR[1] + Rm[4] * wR[4];                                       \
+      cbv[4] = Rm[1] * wR[2] + Rm[4] * wR[5];                                       \
+      cbv[5] = Rm[2] * wR[2] + Rm[5] * wR[5];                                       \
+      cbv[6] = wR[0] * g.r0 + wR[3] * g.r1;                                         \
+      cbv[7] = wR[1] * g.r0 + wR[4] * g.r1;                                         \
+      cbv[8] = wR[2] * g.r0 + wR[5] * g.r1;                                         \
       /* B_ji = w Q^T R of the pair's last-inserted observation (reference :826), */ \
       /* compact: K = w G^T R and X_ij (ba_device.h kWStride)                     */ \
-      double2 *Wp = (double2 *)(Wg + (size_t)(p0 + (int64_t)il_ * dd + jj) * kWStride); \
-      double kk[12];                                                                \
       _Pragma("unroll") for (int r = 0; r < 3; ++r)                                 \
       _Pragma("unroll") for (int c = 0; c < 3; ++c)                                 \
-        kk[r * 3 + c] = w * (G[r] * Rm[c] + G[3 + r] * Rm[3 + c]);                  \
+        kk[r * 3 + c] = G[r] * wR[c] + G[3 + r] * wR[3 + c];                        \
       _Pragma("unroll") for (int r = 0; r < 3; ++r) kk[9 + r] = g.Xij[r];           \
-      _Pragma("unroll") for (int r = 0; r < 6; ++r) Wp[r] = make_double2(kk[2 * r], kk[2 * r + 1]); \
     }                                                                               \
     {                                                                               \
       /* pose side (reference :519-556, :809); fixed poses accumulate zeros */       \
@@ -774,21 +835,22 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
       _Pragma("unroll") for (int c = 0; c < 6; ++c)                                 \
         acc[21 + c] = fma(Q[c], ar0, fma(Q[6 + c], ar1, acc[21 + c]));              \
     }                                                                               \
+    LG_STAMP()                                                                      \
+    LING_FLUSH_FINISH()                                                             \
+    LG_STAMP()                                                                      \
+    /* the LDS area is free now: this step's terms take it */                       \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                          \
     __builtin_amdgcn_wave_barrier();                                                \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
-    /* per-landmark sums in insertion order, one lane per (landmark, value) */      \
-    for (int t_ = lane; t_ < nsum; t_ += 64) {                                      \
-      const int li_ = t_ / 9, v_ = t_ - li_ * 9;                                    \
-      const double *cp_ = cbw + (li_ * no) * 9 + v_;                                \
-      double sacc_ = 0.0;                                                           \
-      for (int q_ = 0; q_ < no; ++q_) sacc_ += cp_[q_ * 9];                         \
-      const int ils_ = il0_ + li_;                                                  \
-      if (ils_ < nl) {                                                              \
-        if (v_ < 6) Cg[(size_t)(l0 + ils_) * 6 + v_] = sacc_;                       \
-        else bg[(size_t)(l0 + ils_) * 3 + (v_ - 6)] = -sacc_;                       \
+    {                                                                               \
+      double *cb = cbw + lane * 9;                                                  \
+      _Pragma("unroll") for (int e_ = 0; e_ < 9; ++e_) cb[e_] = cbv[e_];            \
+      if (lastw && lane_on) {                                                       \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r)                               \
+          stgW_mine[r] = make_double2(kk[2 * r], kk[2 * r + 1]);                    \
       }                                                                             \
     }                                                                               \
+    il0p = il0_;                                                                    \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                          \
     __builtin_amdgcn_wave_barrier();                                                \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
@@ -802,30 +864,40 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
     LING_STEP(2, 1)
     ++st;
   }
+  LING_FLUSH_ISSUE()
+  LING_FLUSH_FINISH()
 #undef LING_STEP
-  // pose-side partial sums of this piece: registers -> LDS [wave][value][lane] ->
-  // one thread per (pose of the group, value)
-#pragma unroll
-  for (int k = 0; k < 27; ++k) cbw[k * 64 + lane] = acc[k];
+#undef LING_FLUSH_ISSUE
+#undef LING_FLUSH_FINISH
+  LG_STAMP()
   {
-    const double tot = block_sum(cost_acc, smc);  // (contains the barrier that publishes red[])
+    const double tot = block_sum(cost_acc, smc);
     if (tid == 0) d.lin_cost_part[cost_idx] = tot;
   }
-  __syncthreads();
-  for (int t = tid; t < dd * 27; t += kBlock) {
-    const int pj = t / 27, e = t - pj * 27;
-    const int sb = slot_b[pj];
-    int se = sb;  // its slots: adjacent pattern entries with the same pose
-    {
-      const int pose_j = d.grp_pat[pat0 + sb].x;
-      while (se < no && d.grp_pat[pat0 + se].x == pose_j) ++se;
+  // pose-side partial sums of this piece: registers -> LDS [wave][value][lane] ->
+  // one thread per (pose of the group, value); two halves of 14 values (LDS area)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 14; ++k)
+      if (half * 14 + k < 27) cbw[k * 64 + lane] = acc[half * 14 + k];
+    __syncthreads();
+    for (int t = tid; t < dd * 14; t += kBlock) {
+      const int pj = t / 14, k = t - pj * 14, e = half * 14 + k;
+      if (e >= 27) continue;
+      const int sb = slot_b[pj], se = slot_e[pj];
+      double sacc = 0.0;
+      for (int w4 = 0; w4 < 4; ++w4)
+        for (int li = 0; li < nlw; ++li)
+          for (int q = sb; q < se; ++q) sacc += red[w4 * kLgArea + k * 64 + li * no + q];
+      d.Apart2[(size_t)(apart0 + pj) * 27 + e] = sacc;
     }
-    double sacc = 0.0;
-    for (int w4 = 0; w4 < 4; ++w4)
-      for (int li = 0; li < nlw; ++li)
-        for (int q = sb; q < se; ++q) sacc += red[(w4 * 27 + e) * 64 + li * no + q];
-    d.Apart2[(size_t)(apart0 + pj) * 27 + e] = sacc;
   }
+  LG_STAMP()
+#ifdef BA_LG_DBG
+  if (lg_on) { for (int q = 0; q < 64; ++q) g_lg_dbg[q] = q < lg_n ? lg_s[q] : 0; }
+#endif
 }
 
 // Damping and landmark inverse (reference :846-856): Cinv_i = (C_i with its
@@ -2186,11 +2258,10 @@ void launch_cost(const DevProblem &d, int sel, int64_t begin, hipStream_t s) {
 
 void launch_lin_landmarks(const DevProblem &d, int sel, hipStream_t s) {
   if (d.lin_chunk0 > 0) {  // covisibility groups: landmark and pose side in one pass
-    const int ng = d.n_grp32 + d.n_grp64;
     if (d.n_cam <= kCamLds)
-      BA_LAUNCH(K_LIN_GRP, k_lin_grp<true>, dim3(ng), dim3(kBlock), s, d, sel);
+      BA_LAUNCH(K_LIN_GRP, k_lin_grp<true>, dim3(d.n_lin_desc), dim3(kBlock), s, d, sel);
     else
-      BA_LAUNCH(K_LIN_GRP, k_lin_grp<false>, dim3(ng), dim3(kBlock), s, d, sel);
+      BA_LAUNCH(K_LIN_GRP, k_lin_grp<false>, dim3(d.n_lin_desc), dim3(kBlock), s, d, sel);
   }
   const int nch = d.n_bchunk - d.lin_chunk0;
   if (nch <= 0) return;
@@ -2226,6 +2297,11 @@ void launch_damp_invert_export(const DevProblem &d, hipStream_t s) {
 #ifdef BA_LL_DBG
 extern "C" int ba_debug_read_ll(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ll_dbg), sizeof(long long) * 32);
+}
+#endif
+#ifdef BA_LG_DBG
+extern "C" int ba_debug_read_lg(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lg_dbg), sizeof(long long) * 64);
 }
 #endif
 #ifdef BA_GRP_DBG

@@ -565,6 +565,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     pl.grp32.clear();
     pl.grp64.clear();
     pl.grp_pat.clear();
+    pl.lin_desc.clear();
     pl.n_apart2 = 0;
     for (const Plan::GrpRange &gr : pl.grp_range) {
       const int64_t p0 = pl.lm_pair_ptr[gr.l0];
@@ -589,6 +590,31 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         }
         if (jj + 1 != gr.d) return "internal: covisibility group pattern / pose count mismatch";
       }
+      // k_lin_grp pieces: runs of `steps` wave steps (4 waves x nlw landmarks each), the
+      // pieces of a group equal up to one step
+      {
+        const int steps_env = getenv("BA_LIN_STEPS") ? std::max(1, atoi(getenv("BA_LIN_STEPS"))) : kLinGrpSteps;
+        const int per_step = 4 * lin_grp_nlw(gr.no);
+        const int nstep = (gr.nl + per_step - 1) / per_step;
+        const int npiece = (nstep + steps_env - 1) / steps_env;
+        for (int c = 0; c < npiece; ++c) {
+          const int s0 = (int)((int64_t)nstep * c / npiece), s1 = (int)((int64_t)nstep * (c + 1) / npiece);
+          Plan::LinDesc ld;
+          const int il0 = s0 * per_step, il1 = std::min(gr.nl, s1 * per_step);
+          ld.l0 = gr.l0 + il0;
+          ld.nl = il1 - il0;
+          ld.d = gr.d;
+          ld.no = gr.no;
+          ld.p0 = p0 + (int64_t)gr.d * il0;
+          ld.o0 = pl.lm_obs_ptr[ld.l0];
+          ld.pat0 = pat0;
+          ld.apart0 = (int32_t)pl.n_apart2;
+          ld.cost_idx = 0;  // set below, after the chunks are known
+          ld.pad_ = 0;
+          pl.n_apart2 += gr.d;
+          if (ld.nl > 0) pl.lin_desc.push_back(ld);
+        }
+      }
       static const int grp_max = getenv("BA_GRP_MAX") ? std::max(12, atoi(getenv("BA_GRP_MAX"))) : kGrpMaxLandmarks;
       const int pieces = (gr.nl + grp_max - 1) / grp_max;
       const int per = (gr.nl + pieces - 1) / pieces;
@@ -599,13 +625,6 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         gd.d = gr.d;
         gd.p0 = p0 + (int64_t)gr.d * c0;
         gd.s0 = (int32_t)pl.slot_blk.size();
-        gd.no = gr.no;
-        gd.o0 = pl.lm_obs_ptr[gd.l0];
-        gd.pat0 = pat0;
-        gd.apart0 = (int32_t)pl.n_apart2;
-        gd.cost_idx = 0;  // set below, after the chunks are known
-        gd.pad_[0] = gd.pad_[1] = 0;
-        pl.n_apart2 += gr.d;
         for (int t = 0; t < kGrpMaxPoses; ++t) gd.pose[t] = t < gr.d ? pl.pair_pose[p0 + t] : 0;
         for (int jj = 0; jj < gr.d; ++jj)
           for (int kk = jj; kk < gr.d; ++kk) {
@@ -862,19 +881,19 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   // chunks' entries), rows of Apart2 per pose ----
   {
     int32_t ci = (int32_t)pl.bchunk_lm.size() - 1;
-    for (auto &g : pl.grp32) g.cost_idx = ci++;
-    for (auto &g : pl.grp64) g.cost_idx = ci++;
+    for (auto &g : pl.lin_desc) g.cost_idx = ci++;
     pl.pose_gpart_ptr.assign(N + 1, 0);
-    if (!pl.lin_groups) pl.n_apart2 = 0;
-    for (auto *gv : {&pl.grp32, &pl.grp64})
-      for (auto &g : *gv)
-        for (int t = 0; pl.lin_groups && t < g.d; ++t) pl.pose_gpart_ptr[g.pose[t] + 1]++;
+    if (!pl.lin_groups) {
+      pl.n_apart2 = 0;
+      pl.lin_desc.clear();
+    }
+    for (auto &g : pl.lin_desc)
+      for (int t = 0; t < g.d; ++t) pl.pose_gpart_ptr[pl.pair_pose[g.p0 + t] + 1]++;
     for (int j = 0; j < N; ++j) pl.pose_gpart_ptr[j + 1] += pl.pose_gpart_ptr[j];
     pl.pose_gpart.assign((size_t)pl.pose_gpart_ptr[N], 0);
     std::vector<int32_t> cur(pl.pose_gpart_ptr.begin(), pl.pose_gpart_ptr.end() - 1);
-    for (auto *gv : {&pl.grp32, &pl.grp64})
-      for (auto &g : *gv)
-        for (int t = 0; pl.lin_groups && t < g.d; ++t) pl.pose_gpart[cur[g.pose[t]]++] = g.apart0 + t;
+    for (auto &g : pl.lin_desc)
+      for (int t = 0; t < g.d; ++t) pl.pose_gpart[cur[pl.pair_pose[g.p0 + t]]++] = g.apart0 + t;
   }
 
   return std::string();

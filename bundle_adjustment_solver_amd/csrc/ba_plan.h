@@ -56,6 +56,8 @@ constexpr int kGrpMaxPoses = 10;    // pose-set sizes handled by the group kerne
 constexpr int kGrpMinLandmarks = 24;  // smaller groups stay on the super-run path
 constexpr int kGrpMaxLandmarks = 1024; // landmarks per group workgroup (larger groups are split)
 constexpr int kGrpMaxObs = 32;        // observations per landmark of a group (one lane each in k_lin_grp)
+constexpr int kLinGrpSteps = 24;      // wave steps per k_lin_grp workgroup (landmarks: 4 waves x nlw x steps)
+inline int lin_grp_nlw(int no) { return 64 / no < 7 ? 64 / no : 7; }  // landmarks per wave step
 
 struct Plan {
   // ---- sizes ----
@@ -134,20 +136,24 @@ struct Plan {
   bool lin_groups = false;               // the groups are also linearised by k_lin_grp
   struct GrpRange { int32_t l0, nl, d, no; };  // landmarks [l0, l0 + nl): d free poses, no observations each
   std::vector<GrpRange> grp_range;
-  struct GrpDesc {                       // one k_schur_grp / k_lin_grp workgroup (96 bytes)
+  struct GrpDesc {                       // one k_schur_grp workgroup (64 bytes)
     int64_t p0;                          // first pair: pair(il, jj) = p0 + d * il + jj
     int32_t l0, nl, d, s0;               // landmarks, pose count, first of its d (d + 1) / 2 slots
     int32_t pose[kGrpMaxPoses];          // ascending optimised pose indices
-    int64_t o0;                          // first observation: obs(il, oo) = o0 + no * il + oo
-    int32_t no, pat0;                    // observations per landmark, first entry of its pattern in grp_pat
-    int32_t apart0, cost_idx;            // first of its d rows of Apart2, its entry of lin_cost_part
-    int32_t pad_[2];
   };
+  struct LinDesc {                       // one k_lin_grp workgroup (48 bytes): a run of landmarks of one group
+    int64_t p0, o0;                      // pair(il, jj) = p0 + d * il + jj;  obs(il, oo) = o0 + no * il + oo
+    int32_t l0, nl, d, no;               // landmarks, free poses, observations per landmark
+    int32_t pat0;                        // first entry of the group's pattern in grp_pat
+    int32_t apart0, cost_idx;            // first of its d rows of Apart2, its entry of lin_cost_part
+    int32_t pad_;
+  };
+  std::vector<LinDesc> lin_desc;
   std::vector<GrpDesc> grp32, grp64;     // d <= 5 / 6 <= d <= 10
   // pattern entry of observation slot oo: {pose (internal index), camera | jj << 16 |
   // optimisable pose << 29 | last writer of its pair << 30}
   std::vector<int32_t> grp_pat;          // 2 ints per slot
-  int64_t n_apart2 = 0;                  // rows (27 doubles) of Apart2 = sum of d over the group pieces
+  int64_t n_apart2 = 0;                  // rows (27 doubles) of Apart2 = sum of d over the k_lin_grp pieces
   std::vector<int32_t> pose_gpart_ptr, pose_gpart;  // N+1 / rows of Apart2 that belong to pose j
   int n_bchunk_grp = 0;                  // back-substitution chunks that cover the grouped landmarks
 };

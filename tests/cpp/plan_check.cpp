@@ -166,13 +166,22 @@ int main(int argc, char **argv) {
             CHECK(pl.sblk_j[blk] == gd.pose[jj] && pl.sblk_k[blk] == gd.pose[kk], "group slot block");
           }
         grp_triples += (int64_t)gd.nl * gd.d * (gd.d + 1) / 2;
-        // observation pattern (k_lin_grp): slot oo of every landmark of the piece is an
-        // observation by pattern pose / camera oo, the slots of a pose are adjacent,
-        // its last slot writes the pair
-        CHECK(gd.no >= gd.d && gd.no <= ba::kGrpMaxObs && gd.o0 == pl.lm_obs_ptr[gd.l0], "group observation base");
+      }
+    // k_lin_grp pieces: tile the grouped landmarks; slot oo of every landmark of a piece
+    // is an observation by pattern pose / camera oo, the slots of a pose are adjacent, its
+    // last slot writes the pair
+    {
+      int nextl = 0;
+      for (const auto &gd : pl.lin_desc) {
+        CHECK(gd.l0 == nextl && gd.nl >= 1, "k_lin_grp pieces tile [0, M_grp)");
+        nextl = gd.l0 + gd.nl;
+        CHECK(gd.no >= gd.d && gd.no <= ba::kGrpMaxObs && gd.o0 == pl.lm_obs_ptr[gd.l0] && gd.p0 == pl.lm_pair_ptr[gd.l0],
+              "piece observation / pair base");
+        CHECK(gd.nl <= ba::kLinGrpSteps * 4 * ba::lin_grp_nlw(gd.no) || getenv("BA_LIN_STEPS"), "piece size");
         CHECK(gd.pat0 >= 0 && (size_t)(gd.pat0 + gd.no) * 2 <= pl.grp_pat.size(), "group pattern range");
         for (int l = gd.l0; l < gd.l0 + gd.nl; ++l) {
           CHECK(pl.lm_obs_ptr[l + 1] - pl.lm_obs_ptr[l] == gd.no, "group landmark observation count");
+          CHECK(pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l] == gd.d, "group landmark degree");
           for (int oo = 0; oo < gd.no; ++oo) {
             const int64_t s = gd.o0 + (int64_t)gd.no * (l - gd.l0) + oo;
             const int32_t pj = pl.grp_pat[2 * (gd.pat0 + oo)], w = pl.grp_pat[2 * (gd.pat0 + oo) + 1];
@@ -180,13 +189,15 @@ int main(int argc, char **argv) {
             CHECK(pl.obs_idx[4 * s + 0] == cam && pl.obs_idx[4 * s + 1] == pj && pl.obs_idx[4 * s + 2] == l,
                   "obs(il, oo) = o0 + no il + oo follows the pattern");
             CHECK(opt == (pj < pl.N), "pattern optimisable flag");
-            if (opt) CHECK(jj < gd.d && gd.pose[jj] == pj, "pattern pose slot");
+            if (opt) CHECK(jj < gd.d && pl.pair_pose[gd.p0 + jj] == pj, "pattern pose slot");
             const int64_t pair = pl.obs_idx[4 * s + 3];
             CHECK(lastw == (pair >= 0), "pattern last-writer flag");
             if (lastw) CHECK(pair == gd.p0 + (int64_t)gd.d * (l - gd.l0) + jj, "pattern pair id");
           }
         }
       }
+      CHECK(nextl == (pl.lin_groups ? pl.M_grp : 0), "k_lin_grp pieces cover the grouped landmarks");
+    }
     for (int l = 0; l < pl.M; ++l) {
       CHECK(gcov[l] == (l < pl.M_grp ? 1 : 0), "landmark %d in %d group pieces", l, gcov[l]);
       CHECK(!(gcov[l] && covered[l]), "landmark %d in a group and in a super-run", l);
@@ -229,18 +240,15 @@ int main(int argc, char **argv) {
     for (int j = 0; j < pl.N; ++j)
       for (int q = pl.pose_gpart_ptr[j]; q < pl.pose_gpart_ptr[j + 1]; ++q) seen[pl.pose_gpart[q]]++;
     for (size_t r = 0; r < seen.size(); ++r) CHECK(seen[r] == 1, "Apart2 row %zu listed %d times", r, seen[r]);
-    if (pl.lin_groups)
-      for (const auto *list : {&pl.grp32, &pl.grp64})
-        for (const auto &gd : *list)
-          for (int t = 0; t < gd.d; ++t) {
-            bool found = false;
-            for (int q = pl.pose_gpart_ptr[gd.pose[t]]; q < pl.pose_gpart_ptr[gd.pose[t] + 1]; ++q)
-              found |= pl.pose_gpart[q] == gd.apart0 + t;
-            CHECK(found, "Apart2 row of (piece, pose) missing from the pose's list");
-          }
-    std::vector<int> cseen(pl.bchunk_lm.size() - 1 + pl.grp32.size() + pl.grp64.size(), 0);
-    for (const auto *list : {&pl.grp32, &pl.grp64})
-      for (const auto &gd : *list) cseen[gd.cost_idx]++;
+    for (const auto &gd : pl.lin_desc)
+      for (int t = 0; t < gd.d; ++t) {
+        const int pj = pl.pair_pose[gd.p0 + t];
+        bool found = false;
+        for (int q = pl.pose_gpart_ptr[pj]; q < pl.pose_gpart_ptr[pj + 1]; ++q) found |= pl.pose_gpart[q] == gd.apart0 + t;
+        CHECK(found, "Apart2 row of (piece, pose) missing from the pose's list");
+      }
+    std::vector<int> cseen(pl.bchunk_lm.size() - 1 + pl.lin_desc.size(), 0);
+    for (const auto &gd : pl.lin_desc) cseen[gd.cost_idx]++;
     for (size_t c = pl.bchunk_lm.size() - 1; c < cseen.size(); ++c) CHECK(cseen[c] == 1, "cost partial entry %zu", c);
   }
   for (size_t c = 0; c + 1 < pl.bchunk_lm.size(); ++c)

@@ -840,6 +840,61 @@ def test_covisibility_groups_equal_the_super_run_path(kind, built):
     assert relerr(Sa, Sb) < 1e-12 and relerr(ra, rb) < 1e-12
 
 
+@pytest.mark.parametrize("shape,env", [
+    ((40, 3000, 5, True), {}),                          # stereo windows of 5: 10 slots, 6 landmarks per wave step
+    ((40, 3000, 5, True), {"BA_LIN_STEPS": "2"}),        # several pieces per group, partial last steps
+    ((40, 3000, 5, True), {"BA_NO_LINGRP": "1"}),        # the chunk / pose-major kernels on the same plan
+    ((30, 2500, 3, True), {"BA_LIN_STEPS": "3"}),        # 6 slots: the 7-landmark cap, 42 of 64 lanes
+    ((30, 2500, 2, False), {}),                         # mono pairs: 2 slots, 14 of 64 lanes
+    ((24, 1500, 10, False), {"BA_LIN_STEPS": "1"}),      # mono windows of 10 (64-wide Schur tiles), one step per piece
+    ((30, 4000, 7, True), {}),                          # 14 slots, 4 landmarks per wave step
+])
+def test_group_linearisation_matches_oracle(shape, env, built):
+    """k_lin_grp (landmark and pose side of the covisibility groups in one pass,
+    lane = (landmark, pattern slot)) against the oracle's blocks: A_j, a_j, C_i,
+    b_i, B_ji per pair and the cost (reference core/full_bundle_adjustment_solver.
+    cpp:716-856), for pattern lengths that fill the wave differently, pieces of
+    one to many wave steps, fixed poses inside the patterns (the first five poses
+    are fixed), Huber weights active; BA_NO_LINGRP=1 runs the chunk and pose-major
+    kernels on the same grouped plan."""
+    import os
+    n_pose, n_pt, window, stereo = shape
+    pr = scenes.scaled_problem(scenes.synthetic_ba_scene(n_pose, n_pt, window, stereo, seed=21, pixel_sigma=1.0))
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        g = make_gpu(pr)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    info = g.get_schur_info()
+    assert info["grouped_landmarks"] > 0.7 * g.M
+    o = O.Oracle(pr)
+    lam, hub = 1.3, 0.7
+    o.linearize(hub)
+    o.damp_invert(lam)
+    g.stage_linearize(lam, hub)
+    assert relerr(g.stage_cost(), o.cost()) < 1e-12
+    A, a = g.get_A()
+    oA, oa = o.get_A()
+    assert blockwise_relerr(A, oA) < RTOL_BLOCK and blockwise_relerr(a, oa) < RTOL_BLOCK
+    Cm, b = g.get_C()
+    oC, ob = o.get_C()
+    assert blockwise_relerr(Cm, oC) < RTOL_BLOCK and blockwise_relerr(b, ob) < RTOL_BLOCK
+    pi, pj, W = g.get_pairs()
+    opi, opj, oW = o.get_pairs()
+    key, okey = np.lexsort((pj, pi)), np.lexsort((opj, opi))
+    assert (pi[key] == opi[okey]).all() and (pj[key] == opj[okey]).all()
+    assert blockwise_relerr(W[key], oW[okey]) < RTOL_BLOCK
+    # the LM path (cost as the by-product of the trial-point linearisation)
+    rows, _ = g.solve(make_options(max_iter=3, thr_step=0, thr_cost=0))
+    orows, _ = o.solve(O.make_options(max_iter=3, thr_step=0, thr_cost=0))
+    for ra, rb in zip(rows, orows):
+        assert ra.iteration_status == rb.iteration_status
+        assert relerr(ra.trial_cost, rb.trial_cost) < 1e-7
+    assert relerr(g.get_poses(), o.get_poses()) < 1e-6
+
+
 @pytest.mark.parametrize("name,scale", [("W20", 0.1), ("DENSE1K", 0.06)])
 def test_off_path_configs_match_oracle(name, scale, built):
     """The two configurations bench.py measures OFF the headline's happy path,

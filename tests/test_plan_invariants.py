@@ -37,6 +37,8 @@ def plan_check(tmp_path_factory):
     (["60", "3000", "20", "1"], {}),                        # windows of 20 poses: landmarks split into pose-group classes
     (["60", "3000", "20", "1"], {"BA_NO_SPLIT": "1"}),      # the same on the global triple list
     (["90", "2000", "37", "2"], {"BA_NO_GROUPS": "1"}),     # four pose groups per landmark, ten classes
+    (["120", "30000", "5", "2"], {"BA_LIN_STEPS": "2"}),    # many k_lin_grp pieces per group
+    (["120", "30000", "5", "2"], {"BA_NO_LINGRP": "1"}),    # groups for the Schur kernel only
 ])
 def test_plan_invariants(plan_check, args, env):
     r = subprocess.run([plan_check] + args, env=dict(os.environ, **env),
