@@ -553,6 +553,8 @@ int ba_finalize(ba_handle *h) {
     // k_lin_grp: observation patterns, pose-side partial sums of the group pieces
     d.lin_chunk0 = pl.lin_groups ? pl.n_bchunk_grp : 0;
     d.n_lin_desc = (int)pl.lin_desc.size();
+    d.n_bs_grp = d.n_lin_desc;
+    d.n_lm_part = d.n_bs_grp + (d.n_bchunk - d.lin_chunk0 + ba::kBsChunks - 1) / ba::kBsChunks;
     d.n_lin_cost = d.n_bchunk + d.n_lin_desc;
     if (h->dalloc(&d.lin_desc, pl.lin_desc.size())) return -1;
     if (d.n_lin_desc)
@@ -581,14 +583,14 @@ int ba_finalize(ba_handle *h) {
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) ||
       h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
       h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
-      h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_bchunk) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
+      h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_lm_part) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
       h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
     return -1;
   HIP_TRY(hipMemset(d.lin_cost_part, 0, (size_t)std::max(1, d.n_lin_cost) * sizeof(double)));
   HIP_TRY(hipMemset(d.x, 0, ((size_t)pl.N * 6 + 64) * sizeof(double)));
   HIP_TRY(hipMemset(d.y, 0, std::max<size_t>(1, (size_t)pl.M * 3) * sizeof(double)));
   HIP_TRY(hipMemset(d.cost_part, 0, ba::kCostGrid * sizeof(double)));
-  HIP_TRY(hipMemset(d.lm_part, 0, (size_t)std::max(1, d.n_bchunk) * 2 * sizeof(double)));
+  HIP_TRY(hipMemset(d.lm_part, 0, (size_t)std::max(1, d.n_lm_part) * 2 * sizeof(double)));
   HIP_TRY(hipMemset(d.pose_part, 0, (2 + 2 * ba::kPoseGrid) * sizeof(double)));
   HIP_TRY(hipMemset(d.scal, 0, 4 * sizeof(double)));
   d.log_cap = 4096;

@@ -118,6 +118,8 @@ struct DevProblem {
   int32_t *pose_gpart_ptr, *pose_gpart;  // rows of Apart2 per pose
   int lin_chunk0;            // k_lin_landmarks starts at this chunk (the chunks before are k_lin_grp's)
   int n_lin_cost;            // entries of lin_cost_part: n_bchunk + k_lin_grp pieces
+  int n_bs_grp;              // group-role workgroups of k_backsub_update (= n_lin_desc, or 0)
+  int n_lm_part;             // entries of lm_part: n_bs_grp + chunk workgroups behind lin_chunk0
   SupDesc *sup_desc;
   uint32_t *sup_lane;  // n_sup*256: lane -> (slot, half, position, lanes per half) of k_schur_lds
   ChunkDesc *chunk_desc;
@@ -149,7 +151,7 @@ struct DevProblem {
   double *lin_cost_part;  // n_bchunk: sum of residual norms per k_lin_landmarks workgroup
   int64_t n_obs_lm;    // observations of optimisable landmarks = the first n_obs_lm of the
                        // landmark-major list (k_lin_landmarks sees exactly these)
-  double *lm_part;     // kLmGrid*2 : model (landmark side), sum |y|
+  double *lm_part;     // n_lm_part*2 : model (landmark side), sum |y| per landmark workgroup of k_backsub_update
   double *pose_part;   // [0..1] totals, then kPoseGrid*2 block partials:
                        // model (pose side), sum |x|
   double *scal;        // exchange buffer 1: [0] cost [1] model est [2] sum|y|
@@ -180,6 +182,7 @@ struct DevProblem {
 };
 
 constexpr int kLinDump = 64 * 4 * 4;
+constexpr int kBsChunks = 4;     // chunks per chunk-role workgroup of k_backsub_update
 constexpr int kCostGrid = 1792;  // 7 waves/SIMD resident on 256 CUs
 constexpr int kLmGrid = 1024;
 constexpr int kPoseGrid = 16;

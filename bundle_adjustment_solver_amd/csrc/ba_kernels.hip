@@ -1860,33 +1860,33 @@ constexpr int kBsRX = (kSchurPairs * 3 + kBlock - 1) / kBlock;
 // through its LDS phases, the W blocks and pose indices of chunk k+1 are already
 // in flight (into the registers chunk k has just released), so only the first
 // chunk of a workgroup pays the full load latency.
-constexpr int kBsChunks = 4;
 #ifdef BA_BS_DBG
 __device__ long long g_bs_dbg[96];
 #define BS_STAMP() { if (bs_on && bs_n < 96) bs_s[bs_n++] = clock64(); }
 #else
 #define BS_STAMP()
 #endif
-__global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
-  __shared__ __attribute__((aligned(16))) double Ws[kSchurPairs * kWStride];
-  __shared__ __attribute__((aligned(16))) double Xs[kSchurPairs * 6];
-  __shared__ double Us[kSchurPairs * 3];
-  __shared__ double sm[8];
-  __shared__ int recs[kBsChunks * 8];
+// LDS of the landmark roles of k_backsub_update (doubles): chunk role = W image,
+// x_j image, u; group role = per wave a W image of <= 64 pairs and their u
+constexpr int kBgLm = 16;  // landmarks per wave step of the group role, at most
+constexpr int kBgArea = 64 * kWStride + 64 * 3 + kBgLm * 12;
+constexpr int kBsLds = (kSchurPairs * (kWStride + 6 + 3) > 4 * kBgArea) ? kSchurPairs * (kWStride + 6 + 3) : 4 * kBgArea;
+
+// Chunk role: bx = index of the workgroup among the chunk workgroups; it handles
+// the chunks lin_chunk0 + bx * kBsChunks ...; part = its entry of lm_part.
+__device__ __forceinline__ void backsub_chunk_body(const DevProblem &d, const int bx, const int part, double *lds,
+                                                   double *sm, int *recs) {
+  double *Ws = lds;                          // kSchurPairs * kWStride
+  double *Xs = Ws + kSchurPairs * kWStride;  // kSchurPairs * 6
+  double *Us = Xs + kSchurPairs * 6;         // kSchurPairs * 3
   const int tid = threadIdx.x;
 #ifdef BA_BS_DBG
   __shared__ long long bs_s[96];
-  const bool bs_on = blockIdx.x == 2000 + kPoseGrid && threadIdx.x == 0;
+  const bool bs_on = bx == 2000 && threadIdx.x == 0;
   int bs_n = 0;
 #endif
   BS_STAMP()
-  if (blockIdx.x < kPoseGrid) {  // pose role (wave-uniform): see pose_update_body
-    if (d.ctrl->done) return;
-    pose_update_body(d, blockIdx.x, sm);
-    return;
-  }
-  const int bx = blockIdx.x - kPoseGrid;
-  const int c0 = bx * kBsChunks;
+  const int c0 = d.lin_chunk0 + bx * kBsChunks;
   const int nk = min(kBsChunks, d.n_bchunk - c0);
   // the workgroup's chunk records -> LDS (vector loads), first one also scalar
   const DevProblem::LmChunk lc0 = d.lm_chunk[c0];
@@ -2048,13 +2048,220 @@ __global__ __launch_bounds__(kBlock, 4) void k_backsub_update(DevProblem d) {
   // one pair of partial sums per workgroup (k_scalars adds them in block order)
   block_sum2(est_acc, nrm_acc, sm);
   if (tid == 0) {
-    d.lm_part[2 * bx + 0] = est_acc;
-    d.lm_part[2 * bx + 1] = nrm_acc;
+    d.lm_part[2 * part + 0] = est_acc;
+    d.lm_part[2 * part + 1] = nrm_acc;
   }
   BS_STAMP()
 #ifdef BA_BS_DBG
   if (bs_on) for (int q = 0; q < 96; ++q) g_bs_dbg[q] = q < bs_n ? bs_s[q] : 0;
 #endif
+}
+
+// Group role: the landmarks of one k_lin_grp piece (ba_plan.h LinDesc: one
+// covisibility group, every landmark seen by the same d free poses, pair (il, jj) =
+// p0 + d il + jj).  The four waves are independent; a wave step covers 64 / d
+// consecutive landmarks, lane = (landmark, pose jj of the group): x_j is a LANE
+// CONSTANT (registers, no gather, no pose indices), the step's W records are one
+// contiguous range, read with consecutive 16-byte pieces two steps ahead and
+// redistributed through the wave's LDS image.  u = B_ji^T x_j per lane; one lane per
+// landmark adds its d vectors in pair order, inverts the damped C_i and updates the
+// point (reference :846-856, :907-925, :443-452).
+__device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int piece, const int part, double *lds,
+                                                 double *sm) {
+  const DevProblem::LinDesc *gp = d.lin_desc + piece;
+  const int64_t p0 = gp->p0;
+  const int l0 = gp->l0, nl = gp->nl, dd = gp->d;
+  const int done = d.ctrl->done;
+  const int cur = d.ctrl->cur;
+  const int lbs = d.ctrl->lcur;
+  const double lp1 = 1.0 + d.ctrl->lambda;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nlwb = 64 / dd < kBgLm ? 64 / dd : kBgLm;  // landmarks per wave step
+  const int ilw = lane / dd, jj = lane - ilw * dd;
+  const bool lane_on = ilw < nlwb;
+  const int pose = d.pair_pose[p0 + jj];
+  if (done) return;
+  double xj[6];
+  {
+    const double2 *xp = (const double2 *)(d.x + (size_t)pose * 6);
+    const double2 a0 = xp[0], a1 = xp[1], a2 = xp[2];
+    xj[0] = a0.x; xj[1] = a0.y; xj[2] = a1.x; xj[3] = a1.y; xj[4] = a2.x; xj[5] = a2.y;
+  }
+  double *__restrict__ Xt = d.pts[cur ^ 1];
+  const double2 *__restrict__ Wg2 = (const double2 *)d.W[lbs];
+  double *Wim = lds + wv * kBgArea;  // 64 * kWStride: W image of the step
+  double *Us = Wim + 64 * kWStride;  // 64 * 3: u per pair
+  double *Lm = Us + 64 * 3;          // kBgLm * 12: C_i (6), b_i (3), X_i (3) of the step's landmarks
+  const int per_step = 4 * nlwb;
+  const int nstep = (nl + per_step - 1) / per_step;
+  auto il0_of = [&](int st) { return (st * 4 + wv) * nlwb; };
+  // The step's landmark data = three contiguous ranges (C_i: 6 nlwb doubles, b_i and
+  // X_i: 3 nlwb each), fetched as 12 nlwb <= 192 doubles, three per lane: entry q =
+  // lane + 64 k of the list {C, b, X} is element lm_e[k] of landmark lm_l[k] of array
+  // lm_p[k] (stride lm_m[k] doubles per landmark); all lane constants.
+  const double *lm_p[3];
+  int lm_l[3], lm_e[3], lm_m[3], lm_q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int q = min(lane + 64 * k, nlwb * 12 - 1);
+    const int nc = nlwb * 6, nb = nlwb * 9;
+    const int a = q < nc ? 0 : (q < nb ? 1 : 2);
+    const int r = q - (a == 0 ? 0 : (a == 1 ? nc : nb));
+    lm_m[k] = a == 0 ? 6 : 3;
+    lm_l[k] = r / lm_m[k];
+    lm_e[k] = r - lm_l[k] * lm_m[k];
+    lm_p[k] = (a == 0 ? d.Cu[lbs] : (a == 1 ? d.b[lbs] : d.pts[cur])) + (size_t)l0 * lm_m[k] + lm_e[k];
+    lm_q[k] = q;
+  }
+  // requests of step ST: its W range (consecutive 16-byte pieces; past the end the
+  // last piece again) and its landmark data (clamped indices: no conditional loads)
+  // (named scalars, not arrays: a register ring declared as an array ended up in
+  //  scratch memory here)
+  double2 rwA0, rwA1, rwA2, rwA3, rwA4, rwA5, rwB0, rwB1, rwB2, rwB3, rwB4, rwB5;
+  double lmA0, lmA1, lmA2, lmB0, lmB1, lmB2;
+#define BSG_ISSUE(R, L, ST)                                                         \
+  {                                                                                 \
+    const int il0_ = il0_of(ST);                                                    \
+    const int nls_ = max(0, min(nlwb, nl - il0_));                                  \
+    const int last_ = max(0, nls_ * dd * 6 - 1);                                    \
+    const int ilb_ = nls_ > 0 ? il0_ : 0;                                           \
+    const int lml_ = max(0, nls_ - 1);                                              \
+    const double2 *src_ = Wg2 + (size_t)(p0 + (int64_t)ilb_ * dd) * 6;              \
+    R##0 = src_[min(lane, last_)];                                                  \
+    R##1 = src_[min(lane + 64, last_)];                                             \
+    R##2 = src_[min(lane + 128, last_)];                                            \
+    R##3 = src_[min(lane + 192, last_)];                                            \
+    R##4 = src_[min(lane + 256, last_)];                                            \
+    R##5 = src_[min(lane + 320, last_)];                                            \
+    L##0 = lm_p[0][(size_t)(ilb_ + min(lm_l[0], lml_)) * lm_m[0]];                  \
+    L##1 = lm_p[1][(size_t)(ilb_ + min(lm_l[1], lml_)) * lm_m[1]];                  \
+    L##2 = lm_p[2][(size_t)(ilb_ + min(lm_l[2], lml_)) * lm_m[2]];                  \
+  }
+#define BSG_WAVE_SYNC()                                                             \
+  {                                                                                 \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                          \
+    __builtin_amdgcn_wave_barrier();                                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
+  }
+  double est_acc = 0.0, nrm_acc = 0.0;
+  double *dump = d.lin_dump + (size_t)((blockIdx.x & 63) * 4 + wv) * 4;
+  const int lml = min(lane, nlwb - 1);  // the landmark of the step this lane does the arithmetic of
+#define BSG_STEP(R, L, TAG)                                                         \
+  {                                                                                 \
+    /* (the two instances must stay two code paths) */                              \
+    asm volatile("; k_backsub_update group step " TAG);                             \
+    const int il0_ = il0_of(st);                                                    \
+    /* registers -> the wave's LDS images (linear) */                               \
+    ((double2 *)Wim)[lane] = R##0;                                                  \
+    ((double2 *)Wim)[lane + 64] = R##1;                                             \
+    ((double2 *)Wim)[lane + 128] = R##2;                                            \
+    ((double2 *)Wim)[lane + 192] = R##3;                                            \
+    ((double2 *)Wim)[lane + 256] = R##4;                                            \
+    ((double2 *)Wim)[lane + 320] = R##5;                                            \
+    Lm[lm_q[0]] = L##0;                                                             \
+    Lm[lm_q[1]] = L##1;                                                             \
+    Lm[lm_q[2]] = L##2;                                                             \
+    BSG_ISSUE(R, L, st + 2)                                                         \
+    BSG_WAVE_SYNC()                                                                 \
+    if (lane_on) {                                                                  \
+      /* u_c = sum_r B_ji[r][c] x_j[r] = K[:,c] . (x_t + x_r x X_ij) */             \
+      const double2 *w2 = (const double2 *)(Wim + lane * kWStride);                 \
+      const double2 k01 = w2[0], k23 = w2[1], k45 = w2[2], k67 = w2[3], k8x = w2[4], xx = w2[5]; \
+      const double X0 = k8x.y, X1 = xx.x, X2 = xx.y;                                \
+      const double e0 = xj[0] + (xj[4] * X2 - xj[5] * X1);                          \
+      const double e1 = xj[1] + (xj[5] * X0 - xj[3] * X2);                          \
+      const double e2 = xj[2] + (xj[3] * X1 - xj[4] * X0);                          \
+      double *u = Us + lane * 3;                                                    \
+      u[0] = fma(k67.x, e2, fma(k23.y, e1, k01.x * e0));                            \
+      u[1] = fma(k67.y, e2, fma(k45.x, e1, k01.y * e0));                            \
+      u[2] = fma(k8x.x, e2, fma(k45.y, e1, k23.x * e0));                            \
+    }                                                                               \
+    BSG_WAVE_SYNC()                                                                 \
+    /* (every lane runs the landmark arithmetic — lanes without a landmark on     */ \
+    /*  the data of the step's last one — and every lane stores, those into a     */ \
+    /*  dump: a store under a branch makes the compiler's vmcnt bookkeeping wait  */ \
+    /*  for all loads in flight, i.e. one full memory latency per step)           */ \
+    {                                                                               \
+      const bool lm_on_ = lane < nlwb && il0_ + lane < nl;                          \
+      double C[6], bi[3], Xi[3];                                                    \
+      _Pragma("unroll") for (int e_ = 0; e_ < 6; ++e_) C[e_] = Lm[lml * 6 + e_];    \
+      _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) bi[e_] = Lm[nlwb * 6 + lml * 3 + e_]; \
+      _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) Xi[e_] = Lm[nlwb * 9 + lml * 3 + e_]; \
+      double bx0 = 0.0, bx1 = 0.0, bx2 = 0.0;  /* sum_j W_ji^T x_j, pair order */   \
+      const double *u = Us + lml * dd * 3;                                          \
+      for (int q_ = 0; q_ < dd; ++q_) {                                             \
+        bx0 += u[q_ * 3 + 0];                                                       \
+        bx1 += u[q_ * 3 + 1];                                                       \
+        bx2 += u[q_ * 3 + 2];                                                       \
+      }                                                                             \
+      double ci[6];                                                                 \
+      {                                                                             \
+        const double cdm[6] = {C[0] * lp1, C[1], C[2], C[3] * lp1, C[4], C[5] * lp1}; \
+        ldlt3_inverse(cdm, ci);                                                     \
+      }                                                                             \
+      const double cb0 = ci[0] * bi[0] + ci[1] * bi[1] + ci[2] * bi[2];             \
+      const double cb1 = ci[1] * bi[0] + ci[3] * bi[1] + ci[4] * bi[2];             \
+      const double cb2 = ci[2] * bi[0] + ci[4] * bi[1] + ci[5] * bi[2];             \
+      const double y0 = cb0 - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);            \
+      const double y1 = cb1 - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);            \
+      const double y2 = cb2 - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);            \
+      const size_t i_ = (size_t)l0 + il0_ + lane;                                   \
+      double *yo = lm_on_ ? d.y + i_ * 3 : dump;                                    \
+      yo[0] = y0; yo[1] = y1; yo[2] = y2;                                           \
+      double *Xo = lm_on_ ? Xt + i_ * 3 : dump;                                     \
+      Xo[0] = Xi[0] + y0;                                                           \
+      Xo[1] = Xi[1] + y1;                                                           \
+      Xo[2] = Xi[2] + y2;                                                           \
+      /* reference :443-452 with the damped C_i (diagonal times 1 + lambda) */      \
+      const double C0 = C[0] * lp1, C3 = C[3] * lp1, C5 = C[5] * lp1;               \
+      double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;                              \
+      const double r0 = y0 * C0 + y1 * C[1] + y2 * C[2];                            \
+      const double r1 = y0 * C[1] + y1 * C3 + y2 * C[4];                            \
+      const double r2 = y0 * C[2] + y1 * C[4] + y2 * C5;                            \
+      e += r0 * y0 + r1 * y1 + r2 * y2;                                             \
+      e += 2.0 * (y0 * bx0 + y1 * bx1 + y2 * bx2);                                  \
+      est_acc += lm_on_ ? e : 0.0;                                                  \
+      nrm_acc += lm_on_ ? sqrt(y0 * y0 + y1 * y1 + y2 * y2) : 0.0;                  \
+    }                                                                               \
+    BSG_WAVE_SYNC()                                                                 \
+  }
+  BSG_ISSUE(rwA, lmA, 0)
+  BSG_ISSUE(rwB, lmB, 1)
+  int st = 0;
+  while (st < nstep) {
+    BSG_STEP(rwA, lmA, "A")
+    if (++st >= nstep) break;
+    BSG_STEP(rwB, lmB, "B")
+    ++st;
+  }
+#undef BSG_STEP
+#undef BSG_ISSUE
+#undef BSG_WAVE_SYNC
+  block_sum2(est_acc, nrm_acc, sm);
+  if (tid == 0) {
+    d.lm_part[2 * part + 0] = est_acc;
+    d.lm_part[2 * part + 1] = nrm_acc;
+  }
+}
+
+// Workgroup roles (by blockIdx, wave-uniform): [0, kPoseGrid) the pose update (see
+// pose_update_body); then one workgroup per covisibility-group piece (n_bs_grp of
+// them); then the chunks behind the groups, kBsChunks per workgroup.  Entry `part`
+// of lm_part = blockIdx - kPoseGrid.
+__global__ __launch_bounds__(kBlock, 3) void k_backsub_update(DevProblem d) {
+  __shared__ __attribute__((aligned(16))) double lds[kBsLds];
+  __shared__ double sm[8];
+  __shared__ int recs[kBsChunks * 8];
+  if (blockIdx.x < kPoseGrid) {
+    if (d.ctrl->done) return;
+    pose_update_body(d, blockIdx.x, sm);
+    return;
+  }
+  const int part = blockIdx.x - kPoseGrid;
+  if (part < d.n_bs_grp)
+    backsub_grp_body(d, part, part, lds, sm);
+  else
+    backsub_chunk_body(d, part - d.n_bs_grp, part, lds, sm, recs);
 }
 #ifdef BA_BS_DBG
 extern "C" int ba_debug_read_bs(long long *out) {
@@ -2099,7 +2306,7 @@ __global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode, 
   if (mode >= 1) {
     const double2 *lp = (const double2 *)d.lm_part;
     // eight independent loads in flight per thread
-    const int n_lp = (d.n_bchunk + kBsChunks - 1) / kBsChunks;  // one entry per backsub workgroup
+    const int n_lp = d.n_lm_part;  // one entry per landmark workgroup of k_backsub_update
     for (int k0 = threadIdx.x; k0 < n_lp; k0 += 8 * kScalBlock) {
       double2 v[8];
 #pragma unroll
@@ -2347,8 +2554,8 @@ void launch_scatter(const DevProblem &d, hipStream_t s) {
 }
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s) {
-  // the first kPoseGrid workgroups update the poses, the others back-substitute
-  BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(kPoseGrid + cdiv(d.n_bchunk, kBsChunks)), dim3(kBlock), s, d);
+  // pose workgroups, covisibility-group pieces, chunk workgroups (see the kernel)
+  BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(kPoseGrid + d.n_lm_part), dim3(kBlock), s, d);
 }
 
 void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s) {
