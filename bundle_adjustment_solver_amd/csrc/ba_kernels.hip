@@ -1371,9 +1371,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_schur_lds(DevProblem d) {
 // four partial tiles are added in wave order at the very end (deterministic) and
 // leave as d (d + 1) / 2 slot partials that k_schur_final sums with the super-run
 // slots.
-// LDS image: entry (k, col) at ((k >> 1) * TW + col) * 2 + (k & 1): the four k rows
+// LDS image: entry (k, col) at (k >> 1) * RS + col * 2 + (k & 1): the four k rows
 // of one MFMA operand read (lanes: col = lane & 15, k = 4 ks + (lane >> 4)) are two
-// 256-byte rows of 16-byte (k even, k odd) cells — two conflict-free passes, no padding.
+// 256-byte rows of 16-byte (k even, k odd) cells — two conflict-free passes; the
+// padding between row pairs (RS) is for the STORES that build the image.
 #ifndef BA_GRP_KRW
 #define BA_GRP_KRW 36
 #endif
@@ -1391,8 +1392,16 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
 #endif
   constexpr int KRW = NT == 2 ? BA_GRP_KRW : 20;  // k rows of a wave's image (multiple of 4)
   constexpr int NTILE = NT * (NT + 1) / 2;
-  __shared__ __attribute__((aligned(16))) double VA[4][KRW * TW];
-  __shared__ __attribute__((aligned(16))) double WB[4][KRW * TW];
+  // doubles per pair of k rows: 2 TW cells + padding.  Without it the row pairs are 128
+  // dwords apart, the bank of a lane's store depends on its pose only and the
+  // landmarks of a chunk collide (6-way); 6 doubles spread them over the banks (2
+  // lanes per bank: the minimum for 64 x 8 bytes).  (NT = 4: no room for padding at
+  // two workgroups per CU.)
+  constexpr int RS = 2 * TW + (NT == 2 ? 6 : 0);
+  constexpr int IMG = (KRW / 2) * RS;
+  __shared__ __attribute__((aligned(16))) double VA[4][IMG];
+  __shared__ __attribute__((aligned(16))) double WB[4][IMG];
+  static_assert(IMG >= 256, "the final reduction uses VA as 4 x 256 doubles");
 #ifdef BA_GRP_DBG
   __shared__ long long gdbg_s[256];
   const bool gdbg_on = blockIdx.x == 600 && threadIdx.x == 0;
@@ -1415,7 +1424,7 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
   const int il = lane / dd, jj = lane - il * dd;  // this lane's pair inside a chunk
   const int nch = (gd.nl + nlw - 1) / nlw;
   double *va = VA[wv], *wb = WB[wv];
-  for (int e = lane; e < KRW * TW; e += 64) {  // rows a full chunk never writes stay zero
+  for (int e = lane; e < IMG; e += 64) {  // rows a full chunk never writes stay zero
     va[e] = 0.0;
     wb[e] = 0.0;
   }
@@ -1439,7 +1448,7 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
   for (int t = 0; t < NTILE; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
   if (wv < nch) GRP_PREFETCH(0, wv)
   if (wv + 4 < nch) GRP_PREFETCH(1, wv + 4)
-#define GRP_IDX(k_, col_) ((((k_) >> 1) * TW + (col_)) * 2 + ((k_) & 1))
+#define GRP_IDX(k_, col_) (((k_) >> 1) * RS + (col_) * 2 + ((k_) & 1))
 #define GRP_STAGE(B)                                                                \
   if (ch < nch) {                                                                   \
     GRP_STAMP()                                                                     \
@@ -1494,8 +1503,8 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                          \
     {                                                                               \
       /* operands of k step ks: rows 4 ks + lk -> cell row 2 ks + (lk >> 1), half lk & 1 */ \
-      const double *ap = va + ((lk >> 1) * TW + lr) * 2 + (lk & 1);                 \
-      const double *bp = wb + ((lk >> 1) * TW + lr) * 2 + (lk & 1);                 \
+      const double *ap = va + (lk >> 1) * RS + lr * 2 + (lk & 1);                   \
+      const double *bp = wb + (lk >> 1) * RS + lr * 2 + (lk & 1);                   \
       double a[NT], b[NT], an[NT], bn[NT];                                          \
       _Pragma("unroll") for (int t = 0; t < NT; ++t) {                              \
         a[t] = ap[32 * t];                                                          \
@@ -1504,8 +1513,8 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
       for (int ks = 0; ks < nks; ++ks) {                                            \
         const int kn = ks + 1 < nks ? ks + 1 : ks; /* operands of the next step first */ \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                            \
-          an[t] = ap[kn * 4 * TW + 32 * t];                                         \
-          bn[t] = bp[kn * 4 * TW + 32 * t];                                         \
+          an[t] = ap[kn * 2 * RS + 32 * t];                                         \
+          bn[t] = bp[kn * 2 * RS + 32 * t];                                         \
         }                                                                           \
         int tile = 0;                                                               \
         _Pragma("unroll") for (int ti = 0; ti < NT; ++ti)                           \
