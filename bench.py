@@ -54,7 +54,7 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
-PMC_SUMMARY = {"C4": "profiles/r02_c4_pmc_fetch_write_v2.txt"}
+PMC_SUMMARY = {"C4": "profiles/r02_c4_pmc_fetch_write_v4.txt"}
 
 
 def pmc_traffic(kernel, config):
@@ -294,13 +294,21 @@ def main():
             B = int(p.lib.ba_num_schur_blocks(p.h))
             si = p.get_schur_info()
             Mg, Pg, Tg = si["grouped_landmarks"], si["grouped_pairs"], si["grouped_triples"]
+            li = p.get_lin_info()
+            Og, Op = li["group_observations"], li["pose_major_observations"]
+            lin_grp = li["group_pieces"] > 0
+            Ml, Pl = (M_glob - Mg, P - Pg) if lin_grp else (M_glob, P)  # the chunk kernel's share
             # algorithmic HBM bytes per launch of each streaming kernel
             # (every array the kernel must read or write, once)
             kbytes = {
                 "k_cost": 24 * n_obs + 24 * M_glob + 96 * n_pose,
+                # grouped landmarks, landmark and pose side in one pass: the observation
+                # stream (uv only: pose and camera are the pattern's), points in; compact
+                # W, undamped C (48) + b (24) out
+                "k_lin_grp": 16 * Og + 24 * Mg + 96 * Pg + 72 * Mg,
                 # observation records + points in; compact W, undamped C (48) + b (24) out
-                "k_lin_landmarks": 32 * n_obs + 24 * M_glob + 96 * P + 72 * M_glob,
-                "k_lin_poses": 24 * O_opt + 24 * M_glob,
+                "k_lin_landmarks": 32 * (n_obs - (Og if lin_grp else 0)) + 24 * Ml + 96 * Pl + 72 * Ml,
+                "k_lin_poses": 24 * Op + 24 * (M_glob if Op else 0),
                 "k_damp_invert": 96 * M_glob,
                 "k_schur_grp": 96 * Pg + 72 * Mg,
                 "k_schur_lds": 96 * (P - Pg) + 72 * (M_glob - Mg) + 4 * (T - Tg),
@@ -352,6 +360,7 @@ def main():
                     "frac": round(kflops[k] / (tot[k] * 1e-3) / 1e12 / peaks[k][1], 4)}
                 for k in kflops if tot.get(k) and kflops[k] > 0}
             result["schur_paths"] = si
+            result["linearisation_paths"] = li
             result["roofline_dense_solve"] = {
                 "bound": "mfma",
                 "achieved": di["flops"] / (dense * 1e-3) / 1e12 if dense else 0,

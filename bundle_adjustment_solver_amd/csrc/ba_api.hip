@@ -1171,6 +1171,18 @@ int ba_get_schur_info(ba_handle *h, int64_t out8[8]) {
   return 0;
 }
 
+int ba_get_lin_info(ba_handle *h, int64_t out4[4]) {
+  if (!h || !h->finalized || !out4) return fail("ba_get_lin_info: bad argument");
+  const ba::Plan &pl = h->plan;
+  int64_t obs = 0;
+  for (const auto &g : pl.lin_desc) obs += (int64_t)g.nl * g.no;
+  out4[0] = (int64_t)pl.lin_desc.size();
+  out4[1] = obs;
+  out4[2] = (int64_t)pl.bchunk_lm.size() - 1 - (pl.lin_groups ? pl.n_bchunk_grp : 0);
+  out4[3] = pl.n_pobs;
+  return 0;
+}
+
 int ba_get_dropped_pivots(ba_handle *h, int64_t *count, int reset) {
   if (!h || !h->finalized || !count) return fail("ba_get_dropped_pivots: bad argument");
   if (use_device(h)) return -1;

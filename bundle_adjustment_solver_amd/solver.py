@@ -448,6 +448,15 @@ class BaProblem:
                     super_runs=int(v[3]), grouped_pairs=int(v[4]), grouped_triples=int(v[5]),
                     group_mfma=int(v[6]), list_triples=int(v[7]))
 
+    def get_lin_info(self):
+        """How the shard is linearised: pieces of the covisibility-group kernel
+        (landmark and pose side in one pass), the observations they cover, chunks left
+        to the chunk kernel, observations on the pose-major list."""
+        v = (C.c_int64 * 4)()
+        check(self.lib.ba_get_lin_info(self.h, v), "ba_get_lin_info")
+        return dict(group_pieces=int(v[0]), group_observations=int(v[1]), chunks=int(v[2]),
+                    pose_major_observations=int(v[3]))
+
     def get_dropped_pivots(self, reset=False):
         """Non-positive pivots met by the reduced-system Cholesky since lm_begin
         (see include/ba_hip.h: where it differs from the reference's pivoted

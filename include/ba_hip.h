@@ -201,6 +201,14 @@ int ba_get_dense_info(ba_handle *h, double out4[4]);
  * for a super-run) }. */
 int ba_get_schur_info(ba_handle *h, int64_t out8[8]);
 
+/* How this shard is linearised and back-substituted (chosen at ba_finalize):
+ * out4 = { workgroups (pieces) of the covisibility-group linearisation kernel —
+ * landmark and pose side of the grouped landmarks in one pass; 0 if the groups
+ * are linearised by the chunk / pose-major kernels —, observations those pieces
+ * cover, landmark chunks left to the chunk kernel, observations on the
+ * pose-major list }. */
+int ba_get_lin_info(ba_handle *h, int64_t out4[4]);
+
 /* The reduced system is factorised by Cholesky WITHOUT pivoting; the
  * reference uses Eigen's diagonally pivoted LDLT with a pseudo-inverted D
  * (reference :905).  A non-positive pivot (<= 1e-300: a pose without

@@ -20,4 +20,5 @@ python tools/pose_only_bench.py > $O/${T}_c5_pose_only.txt 2>&1
 python tools/dense_bench.py --n 5970 > $O/${T}_dense_sweep.txt 2>&1
 tools/rocsolver_bench 5970 5 >> $O/${T}_dense_sweep.txt 2>&1
 ./cpp/build/test_compare > $O/${T}_c5_compare_autodiff_lm.txt 2>&1
+bash tools/sq_counters.sh > $O/${T}_c4_sq_counters.txt 2>&1
 echo done

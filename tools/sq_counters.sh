@@ -1,3 +1,6 @@
+#!/bin/bash
+# SQ counters of the big kernels of one bench run (two rocprofv3 --pmc passes of eight counters each; run on the GPU
+# box):   tools/sq_counters.sh      -> per kernel: wave cycles, VALU-busy, waits, LDS cycles and bank conflicts, ...
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d gpurun_out/pmcA --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmcA.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM -d gpurun_out/pmcB --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmcB.log 2>&1
