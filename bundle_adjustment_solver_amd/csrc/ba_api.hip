@@ -597,11 +597,15 @@ int ba_finalize(ba_handle *h) {
   if (h->dalloc(&d.log, (size_t)d.log_cap)) return -1;
 
   // dense reduced system: tiles of 5 poses (32 columns) or 10 poses (64
-  // columns), eliminated in the order of the level schedule.  The solve is a
-  // chain of dependent launches, one set per level, whose cost is a fixed
-  // latency plus a term proportional to the tile order (C4 on MI355X: 31 us
-  // per level at 32, 47 us at 64): both schedules are built and the cheaper
-  // chain wins (BA_DENSE_NB=32|64 forces one).
+  // columns), eliminated in the order of the level schedule.  Both schedules are
+  // built.  NARROW patterns (every column tile has at most five row tiles below it
+  // besides the rhs block: windows of <= ~15 poses) are latency-bound chains of
+  // dependent launches, one set per level, whose cost is a fixed latency plus a term
+  // proportional to the tile order (measured on MI355X: 16 us per level at 32, 30 us
+  // at 64): the cheaper chain wins.  Wider and dense patterns are bound by the work
+  // per level (row tiles per column, MFMA tile size) and run 1.1-1.9x faster at 64
+  // (W20: 1.08 vs 1.21 ms per iteration, DENSE1K: 10.0 vs 19.0).  BA_DENSE_NB=32|64
+  // forces one.
   {
     const char *nat = getenv("BA_DENSE_NATURAL");
     const char *full = getenv("BA_DENSE_FULL");
@@ -609,7 +613,7 @@ int ba_finalize(ba_handle *h) {
     ba::DenseSchedule cand[2];
     double cost[2];
     const int orders[2] = {32, 64};
-    const double level_us[2] = {31.0, 47.0};
+    const double level_us[2] = {16.0, 30.0};
     for (int k = 0; k < 2; ++k) {
       int ncb_k = 0;
       std::vector<uint8_t> adj;
@@ -618,7 +622,12 @@ int ba_finalize(ba_handle *h) {
       ba::build_dense_schedule(ncb_k, adj, nat && atoi(nat) != 0, orders[k], cand[k]);
       cost[k] = cand[k].nlev * level_us[k];
     }
-    int pick = cost[1] < cost[0] ? 1 : 0;
+    if (getenv("BA_PLAN_STATS"))
+      fprintf(stderr, "dense schedules: nb32 %d tiles %d levels max_rows %d fill %.3f | nb64 %d tiles %d levels max_rows %d fill %.3f\n",
+              cand[0].ncb, cand[0].nlev, cand[0].max_rows, cand[0].fill, cand[1].ncb, cand[1].nlev, cand[1].max_rows,
+              cand[1].fill);
+    const bool narrow = cand[0].max_rows <= 6;
+    int pick = (narrow && cost[0] <= cost[1]) ? 0 : 1;
     if (force && atoi(force) == 32) pick = 0;
     if (force && atoi(force) == 64) pick = 1;
     h->sched = cand[pick];
