@@ -508,6 +508,22 @@ int ba_finalize(ba_handle *h) {
       h->upload(&d.sup_lane, pl.sup_lane) ||
       h->upload(&d.blk_contrib_ptr, pl.blk_contrib_ptr) || h->upload(&d.contrib_slot, pl.contrib_slot))
     return -1;
+  {
+    std::vector<int32_t> bd((size_t)pl.B * 16, 0);
+    for (int64_t bk = 0; bk < pl.B; ++bk) {
+      int32_t *r = bd.data() + 16 * bk;
+      const int64_t c0 = pl.blk_contrib_ptr[bk], c1 = pl.blk_contrib_ptr[bk + 1];
+      r[0] = pl.sblk_j[bk];
+      r[1] = pl.sblk_k[bk];
+      r[2] = (int32_t)c0;
+      r[3] = (int32_t)(c1 - c0);
+      r[4] = pl.sblk_tchunk_ptr[bk];
+      r[5] = pl.sblk_tchunk_ptr[bk + 1] - pl.sblk_tchunk_ptr[bk];
+      for (int t = 0; t < 8; ++t) r[8 + t] = c0 + t < c1 ? pl.contrib_slot[c0 + t] : 0;
+    }
+    if (pl.contrib_slot.size() >= (size_t)INT32_MAX) return fail("too many slot contributions for int32 indices");
+    if (h->upload(&d.blk_desc, bd)) return -1;
+  }
   d.n_sup = (int)pl.sup_desc.size();
   d.n_bchunk = (int)pl.bchunk_lm.size() - 1;
   if (h->upload(&d.bchunk_lm, pl.bchunk_lm)) return -1;

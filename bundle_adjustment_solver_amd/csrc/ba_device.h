@@ -127,6 +127,10 @@ struct DevProblem {
   uint32_t *ltri;
   int64_t *blk_contrib_ptr;
   int32_t *contrib_slot;
+  // the same per block as ONE 64-byte record (k_schur_final reaches its slot partials
+  // after one dependent load): {j, k, first contribution, #contributions, first triple
+  // chunk, #triple chunks, 0, 0, first eight slots}
+  int32_t *blk_desc;
   double *spart2;  // n_slot*kSlotStride slot partial sums (36 of S + 6 of rhs)
   // Linearisation blocks: TWO buffers each, selected by ctrl->lcur.  Every LM
   // iteration linearises at its TRIAL point into the other buffer (the trial cost

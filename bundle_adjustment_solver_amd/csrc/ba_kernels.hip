@@ -1642,7 +1642,12 @@ template <bool DIRECT>
 __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t blk,
                                                  double (*part)[42]) {
   const int q = threadIdx.x / 42, e = threadIdx.x - q * 42;
-  const int j = d.sblk_j[blk], k = d.sblk_k[blk];
+  // ONE record per block: poses, contribution range and the first eight slots
+  const int4 *bq = (const int4 *)(d.blk_desc + 16 * (size_t)blk);
+  const int4 b0 = bq[0], b1 = bq[1], b2 = bq[2], b3 = bq[3];
+  const int done = d.ctrl->done;
+  if (done) return;
+  const int j = b0.x, k = b0.y;
   // what the 42 finishing threads need besides the sums depends on (j, k) only:
   // requested now, one load level earlier than after the barrier
   double pre = 0.0;
@@ -1659,11 +1664,20 @@ __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t bl
   }
   if (q < 6 && (e < 36 || j == k)) {
     double s = 0.0;
-    const int64_t c1 = d.blk_contrib_ptr[blk + 1];
-    for (int64_t cidx = d.blk_contrib_ptr[blk] + q; cidx < c1; cidx += 6)
-      s += d.spart2[(size_t)d.contrib_slot[cidx] * kSlotStride + e];
-    const int ch1 = d.sblk_tchunk_ptr[blk + 1];
-    for (int ch = d.sblk_tchunk_ptr[blk] + q; ch < ch1; ch += 6)
+    const int nc = b0.w;
+    // contributions q, q + 6, ...: the first eight slots are in the record
+    if (q < nc) {
+      const int sl = q == 0 ? b2.x : q == 1 ? b2.y : q == 2 ? b2.z : q == 3 ? b2.w : q == 4 ? b3.x : b3.y;
+      s += d.spart2[(size_t)sl * kSlotStride + e];
+    }
+    if (q + 6 < nc) {
+      const int sl = q == 0 ? b3.z : q == 1 ? b3.w : d.contrib_slot[(size_t)b0.z + q + 6];
+      s += d.spart2[(size_t)sl * kSlotStride + e];
+    }
+    for (int ci = q + 12; ci < nc; ci += 6)
+      s += d.spart2[(size_t)d.contrib_slot[(size_t)b0.z + ci] * kSlotStride + e];
+    const int ch1 = b1.x + b1.y;
+    for (int ch = b1.x + q; ch < ch1; ch += 6)
       s += d.spart[(size_t)ch * kSlotStride + e];
     part[q][e] = s;
   }
@@ -1695,14 +1709,12 @@ __device__ __forceinline__ void schur_final_body(const DevProblem &d, int64_t bl
   }
 }
 __global__ __launch_bounds__(kBlock) void k_schur_final(DevProblem d) {
-  if (d.ctrl->done) return;
   __shared__ double part[6][42];
   schur_final_body<false>(d, blockIdx.x, part);
 }
 // Single GPU: the same, and every value is also placed in the dense matrix
 // (the packed buffer is still written: the readers use it).
 __global__ __launch_bounds__(kBlock) void k_schur_final_direct(DevProblem d) {
-  if (d.ctrl->done) return;
   __shared__ double part[6][42];
   schur_final_body<true>(d, blockIdx.x, part);
 }
@@ -2282,6 +2294,7 @@ extern "C" int ba_debug_read_bs(long long *out) {
 //   mode 0: scal[0] = cost only (initial cost)
 //   mode 1: scal[0] = trial cost, scal[1] = model estimate, scal[2] = sum|y|
 __device__ void control_step(const DevProblem &d);
+__device__ void control_step_vals(const DevProblem &d, double current_cost, double model_est, double sum_y, double sum_x);
 
 // mode 0: cost only; 1: all LM scalars; 2: all LM scalars, then the trust-region
 // control step by the same workgroup (single GPU: nothing to all-reduce in between)
@@ -2368,10 +2381,7 @@ __global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode, 
     d.scal[1] = (mode >= 1) ? te + tpe : 0.0;
     d.scal[2] = (mode >= 1) ? tn : 0.0;
     d.scal[3] = 0.0;
-    if (mode == 2) {
-      __threadfence();
-      control_step(d);
-    }
+    if (mode == 2) control_step_vals(d, tc, (mode >= 1) ? te + tpe : 0.0, (mode >= 1) ? tn : 0.0, tpn);
   }
 }
 
@@ -2383,10 +2393,16 @@ __global__ void k_init_ctrl_cost(DevProblem d) {
 
 // Trust region, convergence and iteration log (reference :928-1007); one thread.
 __device__ void control_step(const DevProblem &d) {
+  if (d.ctrl->done) return;
+  control_step_vals(d, d.scal[0], d.scal[1], d.scal[2], d.pose_part[1]);
+}
+// (the reduction workgroup passes the sums in registers: no store -> fence -> load
+//  round trip in front of the decision)
+__device__ void control_step_vals(const DevProblem &d, const double current_cost, const double model_est,
+                                  const double sum_y, const double sum_x) {
   DevCtrl *c = d.ctrl;
   if (c->done) return;
-  const double current_cost = d.scal[0];
-  const double model = -d.scal[1];
+  const double model = -model_est;
   const double previous_cost = c->prev_cost;
   double rho = (current_cost - previous_cost) * 100.0 / model;
   int status;
@@ -2417,7 +2433,7 @@ __device__ void control_step(const DevProblem &d) {
   const double n_obs = (double)d.n_obs_global;
   const double average_error = current_cost / n_obs;
   const double cost_change = fabs(current_cost - previous_cost);
-  const double total_step = d.scal[2] + d.pose_part[1];
+  const double total_step = sum_y + sum_x;
   const double avg_step = total_step / (double)(d.N + d.M_global);
   bool conv = (avg_step < c->thr_step) || (cost_change < c->thr_cost);
   if (c->iter >= c->max_iter - 1) conv = false;
