@@ -848,6 +848,10 @@ def test_covisibility_groups_equal_the_super_run_path(kind, built):
     ((30, 2500, 2, False), {}),                         # mono pairs: 2 slots, 14 of 64 lanes
     ((24, 1500, 10, False), {"BA_LIN_STEPS": "1"}),      # mono windows of 10 (64-wide Schur tiles), one step per piece
     ((30, 4000, 7, True), {}),                          # 14 slots, 4 landmarks per wave step
+    (("hover", 3, 500, 9), {}),                         # one free pose, nine cameras (global camera path), 27 slots
+    (("hover", 6, 400, 3), {"BA_LIN_STEPS": "5"}),       # 18 slots, d = 4, two fixed poses inside every pattern
+    (("hover", 12, 300, 2), {}),                        # d = 10 (64-wide Schur tiles), 24 slots
+    (("hover", 10, 300, 3), {}),                        # d = 8, 30 slots: 2 landmarks per wave step
 ])
 def test_group_linearisation_matches_oracle(shape, env, built):
     """k_lin_grp (landmark and pose side of the covisibility groups in one pass,
@@ -858,8 +862,11 @@ def test_group_linearisation_matches_oracle(shape, env, built):
     are fixed), Huber weights active; BA_NO_LINGRP=1 runs the chunk and pose-major
     kernels on the same grouped plan."""
     import os
-    n_pose, n_pt, window, stereo = shape
-    pr = scenes.scaled_problem(scenes.synthetic_ba_scene(n_pose, n_pt, window, stereo, seed=21, pixel_sigma=1.0))
+    if shape[0] == "hover":  # every camera of every pose sees every point: ONE group
+        pr = scenes.scaled_problem(scenes.hover_scene(shape[1], shape[2], shape[3], seed=31))
+    else:
+        n_pose, n_pt, window, stereo = shape
+        pr = scenes.scaled_problem(scenes.synthetic_ba_scene(n_pose, n_pt, window, stereo, seed=21, pixel_sigma=1.0))
     for k, v in env.items():
         os.environ[k] = v
     try:
