@@ -317,6 +317,46 @@ __device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
   o[0] = b00; o[1] = b01; o[2] = b02; o[3] = b11; o[4] = b12; o[5] = b22;
 }
 
+// The same inverse on its fast path: C_i with a damped diagonal is symmetric
+// positive definite for every observed landmark, and LDL^T without pivoting is
+// backward stable for such a matrix: three reciprocals (v_rcp_f64 + two Newton
+// steps instead of IEEE divisions) and no pivot search / permutation selects — a
+// third of the instructions of the pivoted routine, which remains the fallback
+// whenever a pivot is not safely positive (relative to the largest diagonal entry):
+// the degenerate cases (never-observed landmark, rank-deficient C_i) keep Eigen's
+// pseudo-inverse semantics exactly.
+__device__ __forceinline__ double rcp_newton(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ void spd3_inverse(const double c[6], double o[6]) {
+  const double a00 = c[0], a01 = c[1], a02 = c[2], a11 = c[3], a12 = c[4], a22 = c[5];
+  const double thr = 1e-12 * fmax(a00, fmax(a11, a22));
+  const double i0 = rcp_newton(a00);
+  const double l10 = a01 * i0, l20 = a02 * i0;
+  const double d1 = fma(-l10, a01, a11);
+  const double t21 = fma(-l20, a01, a12);
+  const double i1 = rcp_newton(d1);
+  const double l21 = t21 * i1;
+  const double d2 = fma(-l21, t21, fma(-l20, a02, a22));
+  const double i2 = rcp_newton(d2);
+  if (!(a00 > thr && d1 > thr && d2 > thr) || !(thr > 0.0)) {  // (also NaN / zero matrices)
+    ldlt3_inverse(c, o);
+    return;
+  }
+  // inverse = L^-T D^-1 L^-1 with L^-1 = [1 0 0; -l10 1 0; l10 l21 - l20, -l21, 1]
+  const double m20 = fma(l10, l21, -l20);
+  const double w2 = m20 * i2, v2 = l21 * i2;
+  o[5] = i2;                                  // (2,2)
+  o[4] = -v2;                                 // (1,2)
+  o[2] = w2;                                  // (0,2)
+  o[3] = fma(l21, v2, i1);                    // (1,1) = i1 + l21^2 i2
+  o[1] = fma(-l10, i1, -(l21 * w2));          // (0,1) = -l10 i1 - l21 m20 i2
+  o[0] = fma(m20, w2, fma(l10 * l10, i1, i0));  // (0,0) = i0 + l10^2 i1 + m20^2 i2
+}
+
 // Observation record as the cost kernel reads it: {camera, pose, point}.  SLIM:
 // the 8-byte copy obs_cp = {camera | pose << 16, point} (problems with fewer
 // than 65 536 cameras and poses) instead of the 16-byte record that also carries
@@ -919,7 +959,7 @@ __global__ __launch_bounds__(kBlock) void k_damp_invert(DevProblem d, int store_
   cd[3] *= lp1;
   cd[5] *= lp1;
   double ci[6];
-  ldlt3_inverse(cd, ci);
+  spd3_inverse(cd, ci);
   double *Io = d.Cinv + (size_t)i * 6;
 #pragma unroll
   for (int k = 0; k < 6; ++k) Io[k] = ci[k];
@@ -1462,7 +1502,7 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
          landmark repeat it, which is cheaper than a kernel + an array for Cinv */    \
       const double cd_[6] = {rc[B][0].x * lp1, rc[B][0].y, rc[B][1].x, rc[B][1].y * lp1, rc[B][2].x, rc[B][2].y * lp1}; \
       double c6[6];                                                                 \
-      ldlt3_inverse(cd_, c6);                                                       \
+      spd3_inverse(cd_, c6);                                                        \
       double w[18];                                                                 \
       _Pragma("unroll") for (int e = 0; e < 9; ++e) w[e] = k9[e];                   \
       _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
@@ -2037,7 +2077,7 @@ __device__ __forceinline__ void backsub_chunk_body(const DevProblem &d, const in
       // here from the undamped C_i instead of being read
       {
         const double cdm[6] = {C[0] * lp1, C[1], C[2], C[3] * lp1, C[4], C[5] * lp1};
-        ldlt3_inverse(cdm, ci);
+        ldlt3_inverse(cdm, ci);  // (the fast path of spd3_inverse costs this loop its registers)
       }
       const double cb0 = ci[0] * bi[0] + ci[1] * bi[1] + ci[2] * bi[2];
       const double cb1 = ci[1] * bi[0] + ci[3] * bi[1] + ci[4] * bi[2];
@@ -2218,7 +2258,7 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
       double ci[6];                                                                 \
       {                                                                             \
         const double cdm[6] = {C[0] * lp1, C[1], C[2], C[3] * lp1, C[4], C[5] * lp1}; \
-        ldlt3_inverse(cdm, ci);                                                     \
+        ldlt3_inverse(cdm, ci); /* (spd3_inverse: spills at this kernel's budget) */ \
       }                                                                             \
       const double cb0 = ci[0] * bi[0] + ci[1] * bi[1] + ci[2] * bi[2];             \
       const double cb1 = ci[1] * bi[0] + ci[3] * bi[1] + ci[4] * bi[2];             \
