@@ -586,7 +586,7 @@ int ba_finalize(ba_handle *h) {
   // per-iteration storage
   for (int k = 0; k < 2; ++k) {
     if (h->dalloc(&d.Cu[k], (size_t)pl.M * 6) || h->dalloc(&d.b[k], (size_t)pl.M * 3) ||
-        h->dalloc(&d.W[k], (size_t)pl.P * ba::kWStride) || h->dalloc(&d.A[k], (size_t)pl.N * 36) ||
+        h->dalloc(&d.W[k], std::max<size_t>(2, (size_t)pl.P * ba::kWStride)) || h->dalloc(&d.A[k], (size_t)pl.N * 36) ||
         h->dalloc(&d.a[k], (size_t)pl.N * 6))
       return -1;
     HIP_TRY(hipMemset(d.W[k], 0, std::max<size_t>(1, (size_t)pl.P * ba::kWStride) * sizeof(double)));

@@ -2137,10 +2137,12 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
   const int lbs = d.ctrl->lcur;
   const double lp1 = 1.0 + d.ctrl->lambda;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int nlwb = 64 / dd < kBgLm ? 64 / dd : kBgLm;  // landmarks per wave step
-  const int ilw = lane / dd, jj = lane - ilw * dd;
-  const bool lane_on = ilw < nlwb;
-  const int pose = d.pair_pose[p0 + jj];
+  // (dd == 0: landmarks seen by fixed poses only: no pair, y_i = Cinv_i b_i)
+  const int ddv = dd > 0 ? dd : 1;
+  const int nlwb = 64 / ddv < kBgLm ? 64 / ddv : kBgLm;  // landmarks per wave step
+  const int ilw = lane / ddv, jj = lane - ilw * ddv;
+  const bool lane_on = dd > 0 && ilw < nlwb;
+  const int pose = dd > 0 ? d.pair_pose[p0 + jj] : 0;
   if (done) return;
   double xj[6];
   {
@@ -2187,7 +2189,7 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
     const int last_ = max(0, nls_ * dd * 6 - 1);                                    \
     const int ilb_ = nls_ > 0 ? il0_ : 0;                                           \
     const int lml_ = max(0, nls_ - 1);                                              \
-    const double2 *src_ = Wg2 + (size_t)(p0 + (int64_t)ilb_ * dd) * 6;              \
+    const double2 *src_ = Wg2 + (dd > 0 ? (size_t)(p0 + (int64_t)ilb_ * dd) * 6 : (size_t)0); \
     R##0 = src_[min(lane, last_)];                                                  \
     R##1 = src_[min(lane + 64, last_)];                                             \
     R##2 = src_[min(lane + 128, last_)];                                            \

@@ -274,7 +274,10 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     std::vector<int32_t> dop(M0, 0);
     for (int i = 0; i < M0; ++i) {
       dop[i] = dopt(i);
-      if (dop[i] >= 1 && dop[i] <= kGrpMaxPoses && deg(i) <= kGrpMaxObs) cand.push_back(i);
+      // (dop == 0: landmarks seen by fixed poses only — the first poses of a trajectory are
+      //  usually fixed — have no pair and no Schur term, but they are linearised and
+      //  back-substituted: groups of them keep those kernels' chunk launches empty)
+      if (dop[i] <= kGrpMaxPoses && deg(i) >= 1 && deg(i) <= kGrpMaxObs) cand.push_back(i);
     }
     std::stable_sort(cand.begin(), cand.end(), less_sig);  // stable: locality order inside a group
     std::vector<uint8_t> grouped(M0, 0);
@@ -615,6 +618,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           if (ld.nl > 0) pl.lin_desc.push_back(ld);
         }
       }
+      if (gr.d == 0) continue;  // no pair, no Schur contribution: no k_schur_grp workgroup
       static const int grp_max = getenv("BA_GRP_MAX") ? std::max(12, atoi(getenv("BA_GRP_MAX"))) : kGrpMaxLandmarks;
       const int pieces = (gr.nl + grp_max - 1) / grp_max;
       const int per = (gr.nl + pieces - 1) / pieces;

@@ -139,9 +139,13 @@ int main(int argc, char **argv) {
   {
     int next = 0;
     for (const auto &gr : pl.grp_range) {
-      CHECK(gr.l0 == next && gr.nl >= ba::kGrpMinLandmarks && gr.d >= 1 && gr.d <= ba::kGrpMaxPoses, "group range");
+      CHECK(gr.l0 == next && gr.nl >= ba::kGrpMinLandmarks && gr.d >= 0 && gr.d <= ba::kGrpMaxPoses, "group range");
       next = gr.l0 + gr.nl;
     }
+    // (groups of landmarks seen by fixed poses only, d = 0, have no Schur piece)
+    std::vector<int> want_piece(pl.M, 0);
+    for (const auto &gr : pl.grp_range)
+      for (int l = gr.l0; l < gr.l0 + gr.nl; ++l) want_piece[l] = gr.d > 0;
     CHECK(next == pl.M_grp && pl.M_grp <= pl.M, "groups tile [0, M_grp)");
     std::vector<int> gcov(pl.M, 0);
     for (const auto *list : {&pl.grp32, &pl.grp64})
@@ -175,7 +179,7 @@ int main(int argc, char **argv) {
       for (const auto &gd : pl.lin_desc) {
         CHECK(gd.l0 == nextl && gd.nl >= 1, "k_lin_grp pieces tile [0, M_grp)");
         nextl = gd.l0 + gd.nl;
-        CHECK(gd.no >= gd.d && gd.no <= ba::kGrpMaxObs && gd.o0 == pl.lm_obs_ptr[gd.l0] && gd.p0 == pl.lm_pair_ptr[gd.l0],
+        CHECK(gd.no >= gd.d && gd.no >= 1 && gd.no <= ba::kGrpMaxObs && gd.o0 == pl.lm_obs_ptr[gd.l0] && gd.p0 == pl.lm_pair_ptr[gd.l0],
               "piece observation / pair base");
         CHECK(gd.nl <= ba::kLinGrpSteps * 4 * ba::lin_grp_nlw(gd.no) || getenv("BA_LIN_STEPS"), "piece size");
         CHECK(gd.pat0 >= 0 && (size_t)(gd.pat0 + gd.no) * 2 <= pl.grp_pat.size(), "group pattern range");
@@ -199,7 +203,7 @@ int main(int argc, char **argv) {
       CHECK(nextl == (pl.lin_groups ? pl.M_grp : 0), "k_lin_grp pieces cover the grouped landmarks");
     }
     for (int l = 0; l < pl.M; ++l) {
-      CHECK(gcov[l] == (l < pl.M_grp ? 1 : 0), "landmark %d in %d group pieces", l, gcov[l]);
+      CHECK(gcov[l] == want_piece[l], "landmark %d in %d group pieces", l, gcov[l]);
       CHECK(!(gcov[l] && covered[l]), "landmark %d in a group and in a super-run", l);
       covered[l] += gcov[l];
     }
