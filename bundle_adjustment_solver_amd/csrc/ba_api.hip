@@ -52,6 +52,9 @@ struct ba_handle {
   // linearisation at the trial point, reset of the factor tiles) that the main
   // stream has not joined yet
   bool side_pending = false;
+  // the factor tiles were reset by the last k_backsub_update (its tile-reset role): the
+  // next iteration needs no k_dense_init
+  bool tiles_ready = false;
   // one LM iteration captured as a hipGraph (single GPU, no timing) and
   // replayed by ba_lm_iterate instead of ~50 separate launches.  Opt-in
   // (BA_GRAPH=1): on ROCm 7.2 / MI355X the replay measured 2.5 % SLOWER than
@@ -150,6 +153,7 @@ int xchg(ba_handle *h, int which) {
 
 // The main stream waits for the side stream's outstanding work (if any).
 void join_side(ba_handle *h) {
+  h->tiles_ready = false;  // (every entry point but the LM iteration itself may dirty the factor tiles)
   if (!h->side_pending) return;
   (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);
   h->side_pending = false;
@@ -186,8 +190,15 @@ int enqueue_iteration(ba_handle *h) {
   mark(h, 0);
   ba::launch_damp_invert(d, s);
   const bool had_side = h->side_pending;
-  if (!had_side)
+  if (!had_side && !h->tiles_ready)
     ba::launch_dense_init(d.L, d.ld, d.col_x, d.zt_I, d.zt_J, d.n_zt, d.nb, &d.ctrl->done, s);
+  h->tiles_ready = false;
+  // NO SIDE STREAM when nothing is left for it: single GPU, every landmark with a free
+  // pose in a covisibility group (no pose-major pass), no cost pass — the reset of the
+  // factor tiles rides in the back-substitution launch (the solve is over by then),
+  // the pose-side sums in the k_scalars launch: no fork / join gaps (6 + 8 us at C4).
+  static const bool no_side_env = !(getenv("BA_FORCE_SIDE") && getenv("BA_FORCE_SIDE")[0] == '1');
+  const bool no_side = no_side_env && !h->ar_fn && d.lin_chunk0 > 0 && d.n_achunk == 0 && d.n_obs_lm == d.n_obs;
   ba::launch_schur_accumulate(d, s);
   join_side(h);  // A_j, a_j of this point and the reset factor tiles come from the side stream
   ba::launch_schur_final(d, direct, s);
@@ -197,9 +208,12 @@ int enqueue_iteration(ba_handle *h) {
   if (!direct) ba::launch_scatter(d, s);
   ba::launch_dense_solve(d, h->sched, h->ddev, s);
   mark(h, 3);
-  ba::launch_backsub_update(d, s);  // trial parameters, model terms, step norms
+  ba::launch_backsub_update(d, s, no_side);  // trial parameters, model terms, step norms
   mark(h, 4);
-  if (ov) {
+  if (no_side) {
+    h->tiles_ready = true;
+    ba::launch_lin_landmarks(d, 1, s);
+  } else if (ov) {
     // pose side of the trial-point linearisation and the reset of the factor
     // tiles: first needed by the NEXT iteration's k_schur_final.  BA_POSE_LATE=1
     // (default) starts them after k_lin_landmarks, beside the control step, the
@@ -233,7 +247,7 @@ int enqueue_iteration(ba_handle *h) {
     mark(h, 7);
     ba::launch_control(d, s);
   } else {  // nothing to exchange: the reduction workgroup also takes the LM decision
-    ba::launch_scalars_and_control(d, 1, s);
+    ba::launch_scalars_and_control(d, 1, s, no_side ? 1 : -1);
     mark(h, 6);
     mark(h, 7);
   }
@@ -748,6 +762,7 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
     h->d.log_cap = opt->max_num_iterations;
   }
   join_side(h);
+  h->tiles_ready = false;
   if (pull_ctrl(h)) return -1;  // keep `cur` and `lcur`
   ba::DevCtrl &c = h->hc;
   c.lambda = (double)opt->initial_lambda;

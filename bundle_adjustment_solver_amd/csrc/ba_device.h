@@ -244,13 +244,14 @@ void launch_damp_invert(const DevProblem &d, hipStream_t s);
 void launch_schur(const DevProblem &d, bool direct, bool with_init, hipStream_t s);
 void launch_schur_accumulate(const DevProblem &d, hipStream_t s);
 void launch_schur_final(const DevProblem &d, bool direct, hipStream_t s);
-void launch_backsub_update(const DevProblem &d, hipStream_t s);
+void launch_backsub_update(const DevProblem &d, hipStream_t s, bool zero_tiles = false);
 void launch_scatter(const DevProblem &d, hipStream_t s);
 // cost_src: 0 = the k_cost partials only (stage API), 1 = the k_lin_landmarks
 // partials (+ the k_cost partials of fixed-landmark observations, if any)
 void launch_scalars_cost_only(const DevProblem &d, int cost_src, hipStream_t s);
 void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s);
-void launch_scalars_and_control(const DevProblem &d, int cost_src, hipStream_t s);  // single GPU
+void launch_scalars_and_control(const DevProblem &d, int cost_src, hipStream_t s,
+                                int finalize_sel = -1);  // single GPU; finalize_sel >= 0: + k_pose_finalize workgroups
 void launch_control(const DevProblem &d, hipStream_t s);
 void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s);
 

@@ -1079,18 +1079,34 @@ __global__ __launch_bounds__(kBlock) void k_lin_poses(DevProblem d, int sel) {
 // A_j (mirrored, UNDAMPED: the readers scale the diagonal by 1 + lambda, reference
 // :833-844) and a_j from the partial sums.
 // One thread per (pose, component): 21 upper + 6 gradient entries.
-__global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d, int sel) {
-  if (d.ctrl->done) return;
+// (the row lists are walked in batches of eight: the index loads of a batch, then its
+//  value loads, are requested together — a dependent index -> value round trip per
+//  row made this kernel a chain of a dozen memory latencies)
+__device__ __forceinline__ void pose_finalize_body(const DevProblem &d, const int sel, const int t) {
   const int lb = sel ? d.ctrl->tlcur : d.ctrl->lcur;
-  const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= d.N * 27) return;
   const int j = t / 27, e = t % 27;
+  const int c0 = d.pose_achunk_ptr[j], c1 = d.pose_achunk_ptr[j + 1];
+  const int q0 = d.pose_gpart_ptr[j], q1 = d.pose_gpart_ptr[j + 1];
   double s = 0.0;
-  for (int ch = d.pose_achunk_ptr[j]; ch < d.pose_achunk_ptr[j + 1]; ++ch)
-    s += d.Apart[(size_t)ch * 27 + e];
+  for (int ch = c0; ch < c1; ch += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = d.Apart[(size_t)min(ch + u, c1 - 1) * 27 + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += ch + u < c1 ? v[u] : 0.0;
+  }
   // rows of the covisibility-group pieces that see this pose (k_lin_grp)
-  for (int q = d.pose_gpart_ptr[j]; q < d.pose_gpart_ptr[j + 1]; ++q)
-    s += d.Apart2[(size_t)d.pose_gpart[q] * 27 + e];
+  for (int q = q0; q < q1; q += 8) {
+    int row[8];
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) row[u] = d.pose_gpart[min(q + u, q1 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = d.Apart2[(size_t)row[u] * 27 + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += q + u < q1 ? v[u] : 0.0;
+  }
   if (e < 21) {
     // upper-triangle index -> (r, c)
     int r = 0, k = e;
@@ -1105,6 +1121,10 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d, int sel)
     const int r = e - 21;
     d.a[lb][(size_t)j * 6 + r] = -s;  // reference :809  a_j -= Q^T (w r)
   }
+}
+__global__ __launch_bounds__(kBlock) void k_pose_finalize(DevProblem d, int sel) {
+  if (d.ctrl->done) return;
+  pose_finalize_body(d, sel, blockIdx.x * kBlock + threadIdx.x);
 }
 
 // rhs_j = a_j - BCinv_b_j (reference :887-888), written to the packed exchange
@@ -2321,6 +2341,16 @@ __global__ __launch_bounds__(kBlock, 3) void k_backsub_update(DevProblem d) {
     return;
   }
   const int part = blockIdx.x - kPoseGrid;
+  if (part >= d.n_lm_part) {  // role: reset of the factor tiles for the NEXT reduced system (k_dense_init)
+    if (d.ctrl->done) return;
+    const int z = part - d.n_lm_part;
+    const int I = d.zt_I[z], J = d.zt_J[z], nb = d.nb;
+    for (int e = threadIdx.x; e < nb * nb; e += kBlock) {
+      const int c = J * nb + e / nb, r = I * nb + e % nb;
+      d.L[(size_t)c * d.ld + r] = (r == c && d.col_x[c] < 0) ? 1.0 : 0.0;
+    }
+    return;
+  }
   if (part < d.n_bs_grp)
     backsub_grp_body(d, part, part, lds, sm);
   else
@@ -2344,7 +2374,16 @@ __device__ void control_step_vals(const DevProblem &d, double current_cost, doub
 // 1: the partials of k_lin_landmarks (cost as a by-product of the linearisation)
 // plus, when fixed landmarks have observations, the k_cost partials of those
 constexpr int kScalBlock = 1024;
-__global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode, int cost_src) {
+// fin_sel >= 0: the workgroups behind the first are k_pose_finalize (sel = fin_sel) —
+// the pose-side sums of the linearisation that has just finished, in this launch
+// instead of on a side stream when nothing else is left for that stream.
+__global__ __launch_bounds__(kScalBlock) void k_scalars(DevProblem d, int mode, int cost_src, int fin_sel) {
+  if (blockIdx.x > 0) {
+    // (no look at ctrl->done: the first workgroup may set it while this one starts, and
+    //  A_j, a_j of the last trial point should be complete; summing again is idempotent)
+    pose_finalize_body(d, fin_sel, (blockIdx.x - 1) * kScalBlock + threadIdx.x);
+    return;
+  }
   if (d.ctrl->done) return;
   double c = 0.0, e = 0.0, n = 0.0, pe = 0.0, pn = 0.0;
   if (cost_src == 0 || d.n_obs_lm < d.n_obs) {  // both rounds of the cost partials requested at once
@@ -2620,17 +2659,19 @@ void launch_scatter(const DevProblem &d, hipStream_t s) {
     BA_LAUNCH(K_SCATTER, k_scatter, dim3(cdiv(n, kBlock)), dim3(kBlock), s, d);
 }
 
-void launch_backsub_update(const DevProblem &d, hipStream_t s) {
-  // pose workgroups, covisibility-group pieces, chunk workgroups (see the kernel)
-  BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(kPoseGrid + d.n_lm_part), dim3(kBlock), s, d);
+void launch_backsub_update(const DevProblem &d, hipStream_t s, bool zero_tiles) {
+  // pose workgroups, covisibility-group pieces, chunk workgroups, [factor-tile reset] (see the kernel)
+  BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(kPoseGrid + d.n_lm_part + (zero_tiles ? d.n_zt : 0)),
+            dim3(kBlock), s, d);
 }
 
 void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 1, cost_src);
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 1, cost_src, -1);
 }
 
-void launch_scalars_and_control(const DevProblem &d, int cost_src, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 2, cost_src);
+void launch_scalars_and_control(const DevProblem &d, int cost_src, hipStream_t s, int finalize_sel) {
+  const int nfin = finalize_sel >= 0 ? cdiv((int64_t)d.N * 27, kScalBlock) : 0;
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1 + nfin), dim3(kScalBlock), s, d, 2, cost_src, finalize_sel);
 }
 
 void launch_control(const DevProblem &d, hipStream_t s) {
@@ -2643,7 +2684,7 @@ void launch_init_ctrl_cost(const DevProblem &d, hipStream_t s) {
 
 // initial-cost scalar reduction (mode 0)
 void launch_scalars_cost_only(const DevProblem &d, int cost_src, hipStream_t s) {
-  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 0, cost_src);
+  BA_LAUNCH(K_SCALARS, k_scalars, dim3(1), dim3(kScalBlock), s, d, 0, cost_src, -1);
 }
 
 }  // namespace ba
