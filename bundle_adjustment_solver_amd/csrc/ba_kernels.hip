@@ -1950,7 +1950,7 @@ __device__ long long g_bs_dbg[96];
 // LDS of the landmark roles of k_backsub_update (doubles): chunk role = W image,
 // x_j image, u; group role = per wave a W image of <= 64 pairs and their u
 constexpr int kBgLm = 16;  // landmarks per wave step of the group role, at most
-constexpr int kBgArea = 64 * kWStride + 64 * 3 + kBgLm * 12;
+constexpr int kBgArea = 64 * kWStride + 64 * 3 + 64 * 12 + 64 * 3;  // W image, u, landmark data and sums of a block
 constexpr int kBsLds = (kSchurPairs * (kWStride + 6 + 3) > 4 * kBgArea) ? kSchurPairs * (kWStride + 6 + 3) : 4 * kBgArea;
 
 // Chunk role: bx = index of the workgroup among the chunk workgroups; it handles
@@ -2174,7 +2174,12 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
   const double2 *__restrict__ Wg2 = (const double2 *)d.W[lbs];
   double *Wim = lds + wv * kBgArea;  // 64 * kWStride: W image of the step
   double *Us = Wim + 64 * kWStride;  // 64 * 3: u per pair
-  double *Lm = Us + 64 * 3;          // kBgLm * 12: C_i (6), b_i (3), X_i (3) of the step's landmarks
+  double *Lm = Us + 64 * 3;          // per step of a block: C_i (6), b_i (3), X_i (3) of its landmarks
+  double *Bx = Lm + 64 * 12;         // 64 * 3: sum_j W_ji^T x_j of the block's landmarks
+  // The landmark arithmetic (3x3 inverse, y_i, model terms: ~250 instructions) runs
+  // once per BLOCK of S = 64 / nlwb steps with one lane per landmark (all lanes
+  // busy), not once per step with nlwb of 64 lanes busy.
+  const int S = 64 / nlwb;
   const int per_step = 4 * nlwb;
   const int nstep = (nl + per_step - 1) / per_step;
   auto il0_of = [&](int st) { return (st * 4 + wv) * nlwb; };
@@ -2228,12 +2233,13 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
   }
   double est_acc = 0.0, nrm_acc = 0.0;
   double *dump = d.lin_dump + (size_t)((blockIdx.x & 63) * 4 + wv) * 4;
-  const int lml = min(lane, nlwb - 1);  // the landmark of the step this lane does the arithmetic of
+  int sb = 0, st_b0 = 0;  // step inside the block, first step of the block
+  const int ls_ = lane / nlwb, lli = lane - ls_ * nlwb;  // landmark phase: lane -> (step of the block, landmark)
+  const int sli = lane / 3, slc = lane - sli * 3;       // sum phase: lane -> (landmark of the step, coordinate)
 #define BSG_STEP(R, L, TAG)                                                         \
   {                                                                                 \
     /* (the two instances must stay two code paths) */                              \
     asm volatile("; k_backsub_update group step " TAG);                             \
-    const int il0_ = il0_of(st);                                                    \
     /* registers -> the wave's LDS images (linear) */                               \
     ((double2 *)Wim)[lane] = R##0;                                                  \
     ((double2 *)Wim)[lane + 64] = R##1;                                             \
@@ -2241,9 +2247,9 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
     ((double2 *)Wim)[lane + 192] = R##3;                                            \
     ((double2 *)Wim)[lane + 256] = R##4;                                            \
     ((double2 *)Wim)[lane + 320] = R##5;                                            \
-    Lm[lm_q[0]] = L##0;                                                             \
-    Lm[lm_q[1]] = L##1;                                                             \
-    Lm[lm_q[2]] = L##2;                                                             \
+    Lm[sb * nlwb * 12 + lm_q[0]] = L##0;                                            \
+    Lm[sb * nlwb * 12 + lm_q[1]] = L##1;                                            \
+    Lm[sb * nlwb * 12 + lm_q[2]] = L##2;                                            \
     BSG_ISSUE(R, L, st + 2)                                                         \
     BSG_WAVE_SYNC()                                                                 \
     if (lane_on) {                                                                  \
@@ -2260,41 +2266,46 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
       u[2] = fma(k8x.x, e2, fma(k45.y, e1, k23.x * e0));                            \
     }                                                                               \
     BSG_WAVE_SYNC()                                                                 \
-    /* (every lane runs the landmark arithmetic — lanes without a landmark on     */ \
-    /*  the data of the step's last one — and every lane stores, those into a     */ \
-    /*  dump: a store under a branch makes the compiler's vmcnt bookkeeping wait  */ \
-    /*  for all loads in flight, i.e. one full memory latency per step)           */ \
-    {                                                                               \
-      const bool lm_on_ = lane < nlwb && il0_ + lane < nl;                          \
+    /* sums of the step's landmarks, pair order: lane (landmark, coordinate) */     \
+    if (lane < nlwb * 3) {                                                          \
+      const double *u = Us + sli * dd * 3 + slc;                                    \
+      double bx_ = 0.0;                                                             \
+      for (int q_ = 0; q_ < dd; ++q_) bx_ += u[q_ * 3];                             \
+      Bx[(sb * nlwb + sli) * 3 + slc] = bx_;                                        \
+    }                                                                               \
+    BSG_WAVE_SYNC()                                                                 \
+    /* landmark arithmetic at the end of a block (uniform branch: LDS and arithmetic */ \
+    /* only); the stores follow unconditionally — lanes and steps with nothing to  */ \
+    /* store write zeros to a dump: a store under a branch makes the compiler's    */ \
+    /* vmcnt bookkeeping wait for all loads in flight (one memory latency per step) */ \
+    const bool do_lm_ = (sb + 1 == S) || (st + 1 >= nstep);                         \
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, xn0 = 0.0, xn1 = 0.0, xn2 = 0.0;           \
+    bool lm_on_ = false;                                                            \
+    size_t i_ = 0;                                                                  \
+    if (do_lm_) {                                                                   \
+      const int il_ = il0_of(st_b0 + ls_) + lli;                                    \
+      lm_on_ = ls_ <= sb && il_ < nl;                                               \
+      i_ = (size_t)l0 + il_;                                                        \
+      const double *lmp = Lm + ls_ * nlwb * 12;                                     \
       double C[6], bi[3], Xi[3];                                                    \
-      _Pragma("unroll") for (int e_ = 0; e_ < 6; ++e_) C[e_] = Lm[lml * 6 + e_];    \
-      _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) bi[e_] = Lm[nlwb * 6 + lml * 3 + e_]; \
-      _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) Xi[e_] = Lm[nlwb * 9 + lml * 3 + e_]; \
-      double bx0 = 0.0, bx1 = 0.0, bx2 = 0.0;  /* sum_j W_ji^T x_j, pair order */   \
-      const double *u = Us + lml * dd * 3;                                          \
-      for (int q_ = 0; q_ < dd; ++q_) {                                             \
-        bx0 += u[q_ * 3 + 0];                                                       \
-        bx1 += u[q_ * 3 + 1];                                                       \
-        bx2 += u[q_ * 3 + 2];                                                       \
-      }                                                                             \
+      _Pragma("unroll") for (int e_ = 0; e_ < 6; ++e_) C[e_] = lmp[lli * 6 + e_];   \
+      _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) bi[e_] = lmp[nlwb * 6 + lli * 3 + e_]; \
+      _Pragma("unroll") for (int e_ = 0; e_ < 3; ++e_) Xi[e_] = lmp[nlwb * 9 + lli * 3 + e_]; \
+      const double bx0 = Bx[lane * 3], bx1 = Bx[lane * 3 + 1], bx2 = Bx[lane * 3 + 2]; \
       double ci[6];                                                                 \
       {                                                                             \
         const double cdm[6] = {C[0] * lp1, C[1], C[2], C[3] * lp1, C[4], C[5] * lp1}; \
-        ldlt3_inverse(cdm, ci); /* (spd3_inverse: spills at this kernel's budget) */ \
+        spd3_inverse(cdm, ci);                                                      \
       }                                                                             \
       const double cb0 = ci[0] * bi[0] + ci[1] * bi[1] + ci[2] * bi[2];             \
       const double cb1 = ci[1] * bi[0] + ci[3] * bi[1] + ci[4] * bi[2];             \
       const double cb2 = ci[2] * bi[0] + ci[4] * bi[1] + ci[5] * bi[2];             \
-      const double y0 = cb0 - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);            \
-      const double y1 = cb1 - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);            \
-      const double y2 = cb2 - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);            \
-      const size_t i_ = (size_t)l0 + il0_ + lane;                                   \
-      double *yo = lm_on_ ? d.y + i_ * 3 : dump;                                    \
-      yo[0] = y0; yo[1] = y1; yo[2] = y2;                                           \
-      double *Xo = lm_on_ ? Xt + i_ * 3 : dump;                                     \
-      Xo[0] = Xi[0] + y0;                                                           \
-      Xo[1] = Xi[1] + y1;                                                           \
-      Xo[2] = Xi[2] + y2;                                                           \
+      y0 = cb0 - (ci[0] * bx0 + ci[1] * bx1 + ci[2] * bx2);                         \
+      y1 = cb1 - (ci[1] * bx0 + ci[3] * bx1 + ci[4] * bx2);                         \
+      y2 = cb2 - (ci[2] * bx0 + ci[4] * bx1 + ci[5] * bx2);                         \
+      xn0 = Xi[0] + y0;                                                             \
+      xn1 = Xi[1] + y1;                                                             \
+      xn2 = Xi[2] + y2;                                                             \
       /* reference :443-452 with the damped C_i (diagonal times 1 + lambda) */      \
       const double C0 = C[0] * lp1, C3 = C[3] * lp1, C5 = C[5] * lp1;               \
       double e = bi[0] * y0 + bi[1] * y1 + bi[2] * y2;                              \
@@ -2305,6 +2316,18 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
       e += 2.0 * (y0 * bx0 + y1 * bx1 + y2 * bx2);                                  \
       est_acc += lm_on_ ? e : 0.0;                                                  \
       nrm_acc += lm_on_ ? sqrt(y0 * y0 + y1 * y1 + y2 * y2) : 0.0;                  \
+    }                                                                               \
+    {                                                                               \
+      double *yo = lm_on_ ? d.y + i_ * 3 : dump;                                    \
+      yo[0] = y0; yo[1] = y1; yo[2] = y2;                                           \
+      double *Xo = lm_on_ ? Xt + i_ * 3 : dump;                                     \
+      Xo[0] = xn0; Xo[1] = xn1; Xo[2] = xn2;                                        \
+    }                                                                               \
+    if (do_lm_) {                                                                   \
+      sb = 0;                                                                       \
+      st_b0 = st + 1;                                                               \
+    } else {                                                                        \
+      ++sb;                                                                         \
     }                                                                               \
     BSG_WAVE_SYNC()                                                                 \
   }
@@ -2331,7 +2354,7 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
 // pose_update_body); then one workgroup per covisibility-group piece (n_bs_grp of
 // them); then the chunks behind the groups, kBsChunks per workgroup.  Entry `part`
 // of lm_part = blockIdx - kPoseGrid.
-__global__ __launch_bounds__(kBlock, 3) void k_backsub_update(DevProblem d) {
+__global__ __launch_bounds__(kBlock, 2) void k_backsub_update(DevProblem d) {
   __shared__ __attribute__((aligned(16))) double lds[kBsLds];
   __shared__ double sm[8];
   __shared__ int recs[kBsChunks * 8];
