@@ -2354,8 +2354,11 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
 // pose_update_body); then one workgroup per covisibility-group piece (n_bs_grp of
 // them); then the chunks behind the groups, kBsChunks per workgroup.  Entry `part`
 // of lm_part = blockIdx - kPoseGrid.
-__global__ __launch_bounds__(kBlock, 2) void k_backsub_update(DevProblem d) {
-  __shared__ __attribute__((aligned(16))) double lds[kBsLds];
+// GROUPS = false: problems without covisibility groups (chunk role only): the LDS of
+// the chunk role alone and four workgroups per CU instead of two.
+template <bool GROUPS>
+__global__ __launch_bounds__(kBlock, GROUPS ? 2 : 4) void k_backsub_update(DevProblem d) {
+  __shared__ __attribute__((aligned(16))) double lds[GROUPS ? kBsLds : kSchurPairs * (kWStride + 6 + 3)];
   __shared__ double sm[8];
   __shared__ int recs[kBsChunks * 8];
   if (blockIdx.x < kPoseGrid) {
@@ -2374,7 +2377,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_backsub_update(DevProblem d) {
     }
     return;
   }
-  if (part < d.n_bs_grp)
+  if (GROUPS && part < d.n_bs_grp)
     backsub_grp_body(d, part, part, lds, sm);
   else
     backsub_chunk_body(d, part - d.n_bs_grp, part, lds, sm, recs);
@@ -2684,8 +2687,11 @@ void launch_scatter(const DevProblem &d, hipStream_t s) {
 
 void launch_backsub_update(const DevProblem &d, hipStream_t s, bool zero_tiles) {
   // pose workgroups, covisibility-group pieces, chunk workgroups, [factor-tile reset] (see the kernel)
-  BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update, dim3(kPoseGrid + d.n_lm_part + (zero_tiles ? d.n_zt : 0)),
-            dim3(kBlock), s, d);
+  const dim3 grid(kPoseGrid + d.n_lm_part + (zero_tiles ? d.n_zt : 0));
+  if (d.n_bs_grp > 0)
+    BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update<true>, grid, dim3(kBlock), s, d);
+  else
+    BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update<false>, grid, dim3(kBlock), s, d);
 }
 
 void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s) {
