@@ -187,6 +187,7 @@ int enqueue_iteration(ba_handle *h) {
   // graph cannot wait for an event of the previous replay
   const bool ov = h->overlap && !h->timing && !h->use_graph;
   const bool direct = !h->ar_fn;  // single GPU: S, rhs are placed in the dense matrix at once
+  h->ddev.flow_ok = !h->use_graph;  // (the dataflow sweep's generation number is a kernel argument)
   mark(h, 0);
   ba::launch_damp_invert(d, s);
   const bool had_side = h->side_pending;
@@ -697,6 +698,17 @@ int ba_finalize(ba_handle *h) {
       return -1;
     dd.col_x = d.col_x;
     dd.read_env();
+    {
+      std::vector<int> order;
+      dd.flow_tail_t0 = ba::dense_flow_order(sc, dd, order);
+      dd.n_flow = (int)order.size();
+      dd.flow_gen = 0;
+      if (h->upload(&dd.flow_order, order) || h->dalloc(&dd.flow_flags, (size_t)std::max(1, ncb)) ||
+          h->dalloc(&dd.flow_ticket, (size_t)1))
+        return -1;
+      HIP_TRY(hipMemset(dd.flow_flags, 0, (size_t)std::max(1, ncb) * sizeof(int)));
+      HIP_TRY(hipMemset(dd.flow_ticket, 0, sizeof(int)));
+    }
     HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
     // tiles (re)initialised per iteration: factor pattern + diagonal + rhs row
     std::vector<int> ztI, ztJ;

@@ -415,11 +415,42 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
   if (tail_cols == 96 && tail_pair)                                                         \
     BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<6, true>), dim3(1), dim3(256), s, L, ld, npad,      \
               tail_c0, dd.xc, x, dd.col_x, done, bad);                                        \
+  if (flow && n_back > 0) {                                                                 \
+    BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow, dim3(n_back), dim3(256), s, L, ld, npad,   \
+              dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, x,    \
+              dd.col_x, done, dd.flow_flags, dd.flow_ticket, ++dd.flow_gen, bad);           \
+  } else                                                                                    \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back, dim3(nt), dim3(256), s, L, ld, npad, t0,        \
               dd.back_desc, dd.rows, Ldiag, dd.xc, x, dd.col_x, done);                      \
   }
+
+// Levels handed to k_chol_tail (the last ones, together 64 or 96 columns, at least two).
+static int dense_tail_levels(const DenseSchedule &sc, const DenseDev &dd, bool fused, int *cols_out) {
+  int tail_levels = 0, tail_cols = 0;
+  if (dd.want_tail && !fused) {
+    for (int l = sc.nlev - 1; l >= 0; --l) {
+      const int cols = (sc.lev_ptr[l + 1] - sc.lev_ptr[l]) * sc.nb;
+      if (tail_cols + cols > kTailCols) break;
+      tail_cols += cols;
+      ++tail_levels;
+    }
+    if (tail_levels < 2 || (tail_cols != 64 && tail_cols != 96)) tail_levels = tail_cols = 0;
+  }
+  if (cols_out) *cols_out = tail_cols;
+  return tail_levels;
+}
+// Positions of the backward sweep's dataflow launch, top level first; returns the first
+// position of the tail block (= their number).
+int dense_flow_order(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &order) {
+  const bool fused = sc.fused_ok && dd.f_desc && dd.want_fused;
+  const int tail_levels = dense_tail_levels(sc, dd, fused, nullptr);
+  order.clear();
+  for (int l = sc.nlev - tail_levels - 1; l >= 0; --l)
+    for (int t = sc.lev_ptr[l]; t < sc.lev_ptr[l + 1]; ++t) order.push_back(t);
+  return sc.lev_ptr[sc.nlev - tail_levels];
+}
 
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const int *done, const DenseSchedule &sc,
@@ -441,21 +472,19 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   (void)row_limit;
   // the last levels (at least two, together at most kTailCols columns) are
   // handed to k_chol_tail: one launch instead of three per level (BA_DENSE_TAIL=0: off)
-  int tail_levels = 0, tail_cols = 0;
-  if (dd.want_tail && !fused) {
-    for (int l = sc.nlev - 1; l >= 0; --l) {
-      const int cols = (sc.lev_ptr[l + 1] - sc.lev_ptr[l]) * sc.nb;
-      if (tail_cols + cols > kTailCols) break;
-      tail_cols += cols;
-      ++tail_levels;
-    }
-    if (tail_levels < 2 || (tail_cols != 64 && tail_cols != 96)) tail_levels = tail_cols = 0;
-  }
+  int tail_cols = 0;
+  const int tail_levels = dense_tail_levels(sc, dd, fused, &tail_cols);
   const int tail_c0 = tail_levels > 0 ? sc.lev_ptr[sc.nlev - tail_levels] * sc.nb : 0;
   // two (independent) tiles in the first level of the block: their panels go side by side
   const bool tail_pair = tail_levels > 0 && sc.nb == 32 &&
                          sc.lev_ptr[sc.nlev - tail_levels + 1] - sc.lev_ptr[sc.nlev - tail_levels] == 2;
   (void)tail_pair;
+  // one dataflow launch for the backward sweep (BA_DENSE_FLOW=0: one launch per level): the
+  // non-tail positions [0, back_t_end), uploaded top level first in dd.flow_order
+  const int back_t_end = sc.lev_ptr[sc.nlev - tail_levels];
+  const int n_back = back_t_end;
+  const bool flow = dd.want_flow && dd.flow_ok && dd.flow_order && dd.n_flow == n_back &&
+                    dd.flow_tail_t0 == back_t_end && !fused && g_ktimer == nullptr;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

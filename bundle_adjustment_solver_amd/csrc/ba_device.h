@@ -273,6 +273,13 @@ struct DenseDev {
   int *col_x = nullptr;   // npad: column -> index into x (6*pose + r) or -1
   double *xc = nullptr;   // npad: solution in column order
   int *bad_pivots = nullptr;  // device counter of non-positive pivots (or null)
+  // dataflow backward sweep (k_chol_back_flow): tile positions top level first, one flag
+  // per tile, the ticket counter; flow_gen = generation number of the next solve (host)
+  int *flow_order = nullptr, *flow_flags = nullptr, *flow_ticket = nullptr;
+  int n_flow = 0, flow_tail_t0 = 0;
+  mutable int flow_gen = 0;
+  bool flow_ok = true;  // false while a hipGraph is captured / replayed (the generation is a kernel argument)
+  bool want_flow = true;
   // BA_DENSE_FUSED / BA_DENSE_SPLIT / BA_DENSE_TAIL as found when the schedule was uploaded
   bool want_fused = false, want_split = false, want_tail = true;
   void read_env() {
@@ -280,6 +287,8 @@ struct DenseDev {
     want_fused = f && f[0] == '1';
     want_split = s && s[0] == '1';
     want_tail = !(t && t[0] == '0');
+    const char *fl = getenv("BA_DENSE_FLOW");
+    want_flow = !(fl && fl[0] == '0');
   }
 };
 struct DenseSchedule;
@@ -289,6 +298,8 @@ void launch_dense_solve(const DevProblem &d, const DenseSchedule &sc,
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const int *done_flag, const DenseSchedule &sc,
                         const DenseDev &dd, hipStream_t s);
+// positions of the dataflow backward sweep (top level first); returns the tail block's first position
+int dense_flow_order(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &order);
 void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
                        const int *zt_J, int n_zt, int nb, const int *done_flag,
                        hipStream_t s);

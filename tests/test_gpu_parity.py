@@ -363,6 +363,35 @@ def test_tail_workgroup_matches_the_level_path(built):
     assert np.abs(A @ x - b).max() < 1e-10 * np.abs(b).max() * n
 
 
+def test_one_stream_iteration_and_dataflow_sweep_equal_their_fallbacks(built):
+    """The LM loop of a grouped scene runs on ONE stream (tile reset as a role of
+    k_backsub_update, pose-side sums as workgroups of k_scalars) and its backward
+    sweep is ONE dataflow launch (ticket order, per-tile flags); BA_FORCE_SIDE=1
+    (side stream with fork / join) and BA_DENSE_FLOW=0 (one launch per level) are
+    the paths every other problem takes: same arithmetic in the same order, so the
+    trajectories must agree bit for bit, iteration by iteration."""
+    import os
+    pr = scenes.scaled_problem(scenes.synthetic_ba_scene(150, 9000, 5, True, seed=33, pixel_sigma=0.3))
+    runs = []
+    for env in ({}, {"BA_FORCE_SIDE": "1"}, {"BA_DENSE_FLOW": "0"}, {"BA_FORCE_SIDE": "1", "BA_DENSE_FLOW": "0"}):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            g = make_gpu(pr)
+            rows, _ = g.solve(make_options(max_iter=10, thr_step=0, thr_cost=0))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        runs.append(([(r.iteration_status, r.trial_cost, r.damping_term) for r in rows], g.get_poses().copy(),
+                     g.get_points()[0].copy()))
+        if not env:
+            assert g.get_lin_info()["pose_major_observations"] == 0 and g.get_lin_info()["chunks"] == 0
+    assert len(runs[0][0]) == 10
+    for other in runs[1:]:
+        assert other[0] == runs[0][0]
+        assert (other[1] == runs[0][1]).all() and (other[2] == runs[0][2]).all()
+
+
 def _compare_solve(pr, iters=6, tol_cost=1e-7, tol_par=1e-6):
     g, o = make_gpu(pr), O.Oracle(pr)
     lam = 3.0
