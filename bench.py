@@ -54,7 +54,7 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
-PMC_SUMMARY = {"C4": "profiles/r02_c4_pmc_fetch_write_v5.txt"}
+PMC_SUMMARY = {"C4": "profiles/r02_c4_pmc_fetch_write_v6.txt"}
 
 
 def pmc_traffic(kernel, config):
