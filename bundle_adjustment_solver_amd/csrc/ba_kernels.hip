@@ -821,6 +821,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
   }
 #define LING_STEP(CUR, NXT2)                                                        \
   {                                                                                 \
+    _Pragma("clang fp contract(fast)")                                              \
     LG_STAMP()                                                                      \
     LING_FLUSH_ISSUE()                                                              \
     {                                                                               \
