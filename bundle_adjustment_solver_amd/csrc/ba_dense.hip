@@ -484,7 +484,7 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   const int back_t_end = sc.lev_ptr[sc.nlev - tail_levels];
   const int n_back = back_t_end;
   const bool flow = dd.want_flow && dd.flow_ok && dd.flow_order && dd.n_flow == n_back &&
-                    dd.flow_tail_t0 == back_t_end && !fused && g_ktimer == nullptr;
+                    dd.flow_tail_t0 == back_t_end && !fused;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {
