@@ -931,6 +931,56 @@ def test_group_linearisation_matches_oracle(shape, env, built):
     assert relerr(g.get_poses(), o.get_poses()) < 1e-6
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_observation_patterns_match_oracle(seed, built):
+    """Covisibility groups with IRREGULAR patterns: every landmark takes one of a few
+    random patterns — a random subset of (pose, camera) pairs of a three-camera rig,
+    poses not contiguous, cameras in any combination, fixed poses inside, one to nine
+    free poses, up to 27 slots — plus a tail of landmarks with unique patterns (chunk
+    kernels).  Blocks, reduced system and a short LM trajectory against the oracle."""
+    rng = np.random.default_rng(100 + seed)
+    n_pose, n_cam, n_pt = 14, 3, 900
+    sc = scenes.hover_scene(n_pose, n_pt, n_cam, seed=40 + seed)
+    # pattern table: subsets of the (pose, camera) pairs
+    pats = []
+    for _ in range(6):
+        poses = rng.choice(n_pose, size=int(rng.integers(2, 10)), replace=False)
+        pat = [(int(j), int(c)) for j in poses for c in range(n_cam) if rng.uniform() < 0.7]
+        pats.append(pat if pat else [(int(poses[0]), 0)])
+    which = rng.integers(0, len(pats), n_pt)
+    keep = np.zeros(sc["obs_pt"].size, bool)
+    key = sc["obs_pose"].astype(np.int64) * n_cam + sc["obs_cam"]
+    for k, pat in enumerate(pats):
+        allowed = np.zeros(n_pose * n_cam, bool)
+        for j, c in pat:
+            allowed[j * n_cam + c] = True
+        keep |= (which[sc["obs_pt"]] == k) & allowed[key]
+    # the last 60 landmarks: individual random patterns (no group)
+    tail = sc["obs_pt"] >= n_pt - 60
+    keep = np.where(tail, rng.uniform(size=keep.size) < 0.4, keep)
+    for k in ("obs_cam", "obs_pose", "obs_pt", "obs_uv"):
+        sc[k] = sc[k][keep]
+    pr = scenes.scaled_problem(sc)
+    g, o = _compare_solve(pr, iters=4, tol_par=1e-5)
+    info, li = g.get_schur_info(), g.get_lin_info()
+    assert info["grouped_landmarks"] > 0.5 * g.M and li["group_pieces"] >= 3 and li["chunks"] >= 1
+    lam, hub = 0.8, 0.9
+    o.linearize(hub)
+    o.damp_invert(lam)
+    g.stage_linearize(lam, hub)
+    A, a = g.get_A()
+    oA, oa = o.get_A()
+    assert blockwise_relerr(A, oA) < RTOL_BLOCK and blockwise_relerr(a, oa) < RTOL_BLOCK
+    Cm, b = g.get_C()
+    oC, ob = o.get_C()
+    assert blockwise_relerr(Cm, oC) < RTOL_BLOCK and blockwise_relerr(b, ob) < RTOL_BLOCK
+    pi, pj, W = g.get_pairs()
+    opi, opj, oW = o.get_pairs()
+    key, okey = np.lexsort((pj, pi)), np.lexsort((opj, opi))
+    assert (pi[key] == opi[okey]).all() and (pj[key] == opj[okey]).all()
+    assert blockwise_relerr(W[key], oW[okey]) < RTOL_BLOCK
+
+
 @pytest.mark.parametrize("name,scale", [("W20", 0.1), ("DENSE1K", 0.06)])
 def test_off_path_configs_match_oracle(name, scale, built):
     """The two configurations bench.py measures OFF the headline's happy path,
