@@ -7,10 +7,15 @@ A "step" is one LM iteration (linearise -> Schur -> dense reduced solve ->
 back-substitution/update -> trial cost -> trust-region control; reference
 core/full_bundle_adjustment_solver.cpp:709-1007) of BASELINE.json's flagship
 workload C4 (stereo, 1 000 poses / 500 000 landmarks / 5 000 000
-observations, synthetic, seeded).  N > 1: one process per GPU (torchrun),
-landmarks sharded across ranks, one RCCL all-reduce of the reduced camera
-system per iteration (strong scaling: the problem is fixed).  Inputs are
-resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+observations, synthetic, seeded).  N > 1: one process per GPU, landmarks
+sharded across ranks, one RCCL all-reduce of the packed reduced camera system
+and one of four LM scalars per iteration, issued from C++ inside the library
+(ba_rccl_allreduce_hook) — strong scaling by default (the problem is fixed),
+`--weak` multiplies landmarks and observations by N at fixed poses.  Started
+either by torchrun (RANK / WORLD_SIZE in the environment) or as plain
+`python bench.py --gpus N`: the script then starts the N ranks itself, as
+child processes, before anything touches the GPU.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -110,6 +115,27 @@ def dense_faithful_baseline(O, scenes, config, pr, huber):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD
+    processes of torch.distributed.run (nothing in this process has touched the
+    GPU or imported torch yet; no exec), relay their output and exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +150,9 @@ def main():
                          "(SURVEY.md 8d: the headline is 0, second run 0.5)")
     ap.add_argument("--huber", type=float, default=1.0,
                     help="threshold_huber_loss (solver units of 0.01 px)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: landmarks and observations x N at fixed "
+                         "poses (the default is strong: the problem is fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -133,19 +162,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # native artefacts are checked once, here, so the ranks find them built
+        import __graft_entry__ as ge
+        ge.build(only_if_missing=True)
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit("--gpus %d but WORLD_SIZE=1" % args.gpus)
 
     # native artefacts first, before anything initialises the GPU or the process
     # group: rank 0 alone checks the source stamps (and rebuilds what is stale);
     # the other ranks block in init_process_group / the barrier below until it
     # has joined, so nobody loads a library that is being rewritten
+    import torch
+    import torch.distributed as dist
     import __graft_entry__ as ge
     if rank == 0:
         ge.build(only_if_missing=True)
 
-    import torch
-    import torch.distributed as dist
     # BA_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs
     # than ranks (ranks share cards, the exchange is staged through the host);
     # the line is then labelled as a rehearsal, never a result.
@@ -153,7 +187,8 @@ def main():
     rehearsal = backend != "nccl"
     if rehearsal:
         local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
+    if torch.cuda.device_count() > 0:   # (without a GPU ba_create below fails loudly: no CPU path)
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -167,10 +202,10 @@ def main():
     from bundle_adjustment_solver_amd import scenes
     from bundle_adjustment_solver_amd._lib import make_options
     from bundle_adjustment_solver_amd.solver import BaProblem
-    from oracle import oracle_py as O
 
     t_gen = time.time()
-    sc = scenes.config_scene(args.config, args.scale, args.sigma)
+    factor = world if args.weak else 1
+    sc = scenes.config_scene(args.config, args.scale, args.sigma, landmark_factor=factor)
     pr = scenes.scaled_problem(sc)
     t_gen = time.time() - t_gen
 
@@ -187,10 +222,24 @@ def main():
     t_fin = time.time()
     p.finalize()
     t_fin = time.time() - t_fin
+    n_ranks_seen = 1
+    exchange = "none"
     if world > 1:
-        from bundle_adjustment_solver_amd.sharding import TorchExchange
-        keep.append(TorchExchange(p, dist, torch.device("cuda", local_rank),
-                                  stage_host=rehearsal))
+        # the per-iteration collectives: RCCL from C++ inside the library (no Python
+        # between the kernels); BA_BENCH_EXCHANGE=torch keeps them in torch.distributed
+        # (a Python callback twice per iteration), which is also what a gloo rehearsal
+        # uses, staged through the host
+        from bundle_adjustment_solver_amd.sharding import RcclExchange, TorchExchange
+        if rehearsal or os.environ.get("BA_BENCH_EXCHANGE") == "torch":
+            keep.append(TorchExchange(p, dist, torch.device("cuda", local_rank),
+                                      stage_host=rehearsal))
+            n_ranks_seen = dist.get_world_size()
+            exchange = "torch.distributed/%s%s" % (backend, " (host-staged)" if rehearsal else "")
+        else:
+            ex = RcclExchange(p, dist, rank, world, local_rank)
+            keep.append(ex)
+            n_ranks_seen = ex.size()
+            exchange = "RCCL all-reduce issued by libba_hip.so (ba_rccl_allreduce_hook)"
 
     n_obs = int(pr["obs_cam"].shape[0])
     N = p.N
@@ -228,14 +277,18 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     result = {
         "metric": "lm_iterations_per_sec",
-        "value": args.steps / elapsed,
-        "unit": "it/s",
+        # strong: LM iterations/s of the fixed problem.  weak: the problem is N times
+        # the one-GPU problem, so the whole-job rate is N x (iterations/s) in units of
+        # one-GPU-problem iterations (= obs_iterations_per_sec / observations of the
+        # one-GPU problem)
+        "value": args.steps / elapsed * factor,
+        "unit": "it/s" if factor == 1 else "it/s x N (iterations of the N-times problem x N)",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if args.weak else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -243,14 +296,17 @@ def main():
             "workload": WORKLOADS[args.config] +
             ("" if args.scale == 1.0 else " (scaled x%g, debug)" % args.scale) +
             ("" if args.sigma == 0.0 else ", pixel noise sigma %g px" % args.sigma) +
-            ("" if args.huber == 1.0 else ", huber %g" % args.huber),
+            ("" if args.huber == 1.0 else ", huber %g" % args.huber) +
+            ("" if factor == 1 else ", landmarks and observations x%d (weak scaling)" % factor),
             "n_opt_poses": N, "n_opt_landmarks": M_glob,
             "n_observations": n_obs,
             "parallelism": ("landmark-shard x%d + all-reduce(S|rhs)" % world +
                             (" (REHEARSAL: %s, shared GPU)" % backend
                              if rehearsal else ""))
             if world > 1 else "single GPU",
+            "exchange": exchange,
         },
+        "n_ranks_seen": n_ranks_seen,
         "obs_iterations_per_sec": n_obs * args.steps / elapsed,
         "final_cost": rows[-1].cost if rows else None,
         "host_prep_s": {"scene_gen": t_gen, "finalize_upload": t_fin},
@@ -377,6 +433,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the box's host cores, 1 thread -------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_py as O   # the checker: this leg only
         o = O.Oracle(pr)
         t = time.perf_counter()
         orows, _ = o.solve(O.make_options(max_iter=1, thr_step=-1.0,

@@ -94,6 +94,14 @@ SIGNATURES = {
     "ba_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
     "ba_reduce_buffer_size": (C.c_int64, [_P, C.c_int]),
     "ba_bind_reduce_buffer": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "ba_gather_points": (C.c_int, [_P]),
+    "ba_rccl_available": (C.c_int, []),
+    "ba_rccl_get_unique_id": (C.c_int, [_U8]),
+    "ba_rccl_comm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, _U8, C.c_int]),
+    "ba_rccl_comm_size": (C.c_int, [_P]),
+    "ba_rccl_comm_calls": (C.c_int64, [_P]),
+    "ba_rccl_comm_destroy": (None, [_P]),
+    "ba_rccl_allreduce_hook": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
     "ba_solve": (C.c_int, [_P, C.POINTER(BaOptions), C.POINTER(BaIterInfo),
                            C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ba_lm_begin": (C.c_int, [_P, C.POINTER(BaOptions)]),

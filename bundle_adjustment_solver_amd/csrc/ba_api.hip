@@ -16,6 +16,7 @@
 
 namespace ba {
 void launch_damp_invert_export(const DevProblem &d, hipStream_t s);
+void set_last_error(const std::string &m);  // (also used by ba_rccl.cpp)
 }
 
 namespace {
@@ -26,6 +27,10 @@ int fail(const std::string &m) {
   g_err = m;
   return -1;
 }
+
+}  // namespace
+void ba::set_last_error(const std::string &m) { g_err = m; }
+namespace {
 
 #define HIP_TRY(expr)                                                        \
   do {                                                                       \
@@ -81,7 +86,14 @@ struct ba_handle {
   std::vector<void *> allocs;
   ba_allreduce_fn ar_fn = nullptr;
   void *ar_user = nullptr;
-  int64_t xbuf_n[2] = {0, 0};
+  int64_t xbuf_n[3] = {0, 0, 0};
+  // exchange buffer 2: every point of the full problem in user order (3 doubles each),
+  // rows of points this shard does not own zero — ba_gather_points
+  double *gbuf = nullptr;
+  bool gbuf_bound = false;
+  int32_t *pt_user_dev = nullptr;       // pt_user_of_int on the device (lazily)
+  std::vector<double> gathered;         // result of the last ba_gather_points (host, user order)
+  bool gathered_valid = false;
   ba::DevCtrl hc;  // host mirror for the stage API
   bool timing = false;
   hipEvent_t ev[ST_N + 1];
@@ -127,6 +139,10 @@ struct ba_handle {
     po_dev = po_host = nullptr;
     po_cap = 0;
     po_part = nullptr;  // was in `allocs`
+    gbuf = nullptr;     // (its own: in `allocs`; bound: the caller's)
+    gbuf_bound = false;
+    pt_user_dev = nullptr;
+    gathered_valid = false;
     finalized = false;
   }
 };
@@ -670,6 +686,7 @@ int ba_finalize(ba_handle *h) {
     d.ld = d.npad + nb;
     h->xbuf_n[0] = pl.B * 36 + 6 * (int64_t)pl.N;
     h->xbuf_n[1] = 4;
+    h->xbuf_n[2] = 3 * (int64_t)pl.n_pt_global;
     if (h->dalloc(&d.Spk, (size_t)h->xbuf_n[0])) return -1;
     if (h->dalloc(&d.L, (size_t)d.npad * d.ld)) return -1;
     if (h->dalloc(&d.Ldiag, (size_t)ncb * ba::dense_ws_per_block(nb))) return -1;
@@ -744,19 +761,23 @@ int ba_set_allreduce(ba_handle *h, ba_allreduce_fn fn, void *user) {
 }
 
 int64_t ba_reduce_buffer_size(ba_handle *h, int which) {
-  if (!h || !h->finalized || which < 0 || which > 1) return -1;
+  if (!h || !h->finalized || which < 0 || which > 2) return -1;
   return h->xbuf_n[which];
 }
 
 int ba_bind_reduce_buffer(ba_handle *h, int which, void *dev_ptr, int64_t n) {
   if (!h || !h->finalized) return fail("ba_bind_reduce_buffer: not finalized");
   h->drop_graph();
-  if (which < 0 || which > 1 || !dev_ptr || n < h->xbuf_n[which])
+  if (which < 0 || which > 2 || !dev_ptr || n < h->xbuf_n[which])
     return fail("ba_bind_reduce_buffer: bad argument");
   if (which == 0)
     h->d.Spk = (double *)dev_ptr;
-  else
+  else if (which == 1)
     h->d.scal = (double *)dev_ptr;
+  else {
+    h->gbuf = (double *)dev_ptr;  // (a buffer of the library's own stays in `allocs`)
+    h->gbuf_bound = true;
+  }
   return 0;
 }
 
@@ -775,6 +796,7 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
   }
   join_side(h);
   h->tiles_ready = false;
+  h->gathered_valid = false;
   if (pull_ctrl(h)) return -1;  // keep `cur` and `lcur`
   ba::DevCtrl &c = h->hc;
   c.lambda = (double)opt->initial_lambda;
@@ -812,6 +834,7 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
 int ba_lm_iterate(ba_handle *h, int n) {
   if (!h || !h->lm_begun) return fail("ba_lm_iterate: call ba_lm_begin first");
   if (use_device(h)) return -1;
+  h->gathered_valid = false;
   // Graph replay: the kernels early-exit on the device-side `done` word and
   // take the whole problem by value, so one captured iteration is valid until
   // the problem, the stream or the exchange buffers change (drop_graph()).
@@ -851,6 +874,17 @@ int ba_lm_sync(ba_handle *h, ba_iter_info *out, int cap, int *n_iter,
   if (h->side_pending) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);  // (stays pending: the
   //   next iteration joins it again, which is harmless)
   if (pull_ctrl(h)) return -1;
+  {
+    // A hand-off of a dataflow sweep of the reduced solve that timed out (bounded
+    // polls, ba_dense_tile.inc) left x partly unsolved: the device added kFlowTimeout
+    // to the pivot counter.  That is an ERROR of the solve, not a dropped pivot.
+    int bp = 0;
+    HIP_TRY(hipMemcpy(&bp, h->ddev.bad_pivots, sizeof(int), hipMemcpyDeviceToHost));
+    if (bp >= ba::kFlowTimeout)
+      return fail("ba_lm_sync: a dataflow hand-off of the reduced solve timed out (" +
+                  std::to_string(bp / ba::kFlowTimeout) + " polls gave up); the iterations since ba_lm_begin "
+                  "are invalid. BA_DENSE_FLOW=0 selects the per-level launches");
+  }
   const int n = h->hc.iter;
   if (n_iter) *n_iter = n;
   if (converged) *converged = h->hc.converged;
@@ -964,6 +998,7 @@ int ba_stage_scalars(ba_handle *h, double *trial_cost, double *model_change,
 int ba_stage_commit(ba_handle *h, int accept) {
   if (!h || !h->finalized) return fail("ba_stage_commit: not finalized");
   if (use_device(h)) return -1;
+  h->gathered_valid = false;
   if (pull_ctrl(h)) return -1;
   if (accept) h->hc.cur ^= 1;
   if (push_ctrl(h)) return -1;
@@ -1010,8 +1045,47 @@ int ba_get_poses(ba_handle *h, double *T_jw12) {
   return 0;
 }
 
+// rows of `src` (internal point order) to user order in `dst`
+__global__ void k_points_to_user(const double *__restrict__ src, const int32_t *__restrict__ user_of_int, int n,
+                                 double *__restrict__ dst) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const size_t u = (size_t)user_of_int[q] * 3;
+  dst[u + 0] = src[(size_t)q * 3 + 0];
+  dst[u + 1] = src[(size_t)q * 3 + 1];
+  dst[u + 2] = src[(size_t)q * 3 + 2];
+}
+
+int ba_gather_points(ba_handle *h) {
+  if (!h || !h->finalized) return fail("ba_gather_points: not finalized");
+  if (use_device(h)) return -1;
+  h->gathered_valid = false;
+  if (!h->ar_fn || h->world <= 1) return 0;  // one shard owns every point: nothing to gather
+  const ba::Plan &pl = h->plan;
+  const size_t n3 = (size_t)pl.n_pt_global * 3;
+  if (!h->gbuf && h->dalloc(&h->gbuf, n3)) return -1;
+  if (!h->pt_user_dev && h->upload(&h->pt_user_dev, pl.pt_user_of_int)) return -1;
+  if (pull_ctrl(h)) return -1;  // `cur` (synchronises the stream)
+  join_side(h);
+  HIP_TRY(hipMemsetAsync(h->gbuf, 0, n3 * sizeof(double), h->stream));
+  if (pl.n_pt > 0)
+    hipLaunchKernelGGL(k_points_to_user, dim3((pl.n_pt + 255) / 256), dim3(256), 0, h->stream,
+                       (const double *)h->d.pts[h->hc.cur], (const int32_t *)h->pt_user_dev, pl.n_pt, h->gbuf);
+  if (h->ar_fn(h->ar_user, 2, (void *)h->gbuf, (int64_t)n3, (void *)h->stream) != 0)
+    return fail("ba_gather_points: all-reduce hook returned an error");
+  if (download(h->gathered, h->gbuf, n3, h->stream)) return -1;
+  HIP_TRY(hipGetLastError());
+  h->gathered_valid = true;
+  return 0;
+}
+
 int ba_get_points(ba_handle *h, double *X3, uint8_t *owned_mask) {
   if (!h || !h->finalized || !X3) return fail("ba_get_points: bad argument");
+  if (h->gathered_valid) {  // after ba_gather_points: every point of the full problem
+    std::memcpy(X3, h->gathered.data(), h->gathered.size() * sizeof(double));
+    if (owned_mask) std::memset(owned_mask, 1, (size_t)h->plan.n_pt_global);
+    return 0;
+  }
   if (use_device(h) || pull_ctrl(h)) return -1;
   std::vector<double> buf;
   if (download(buf, h->d.pts[h->hc.cur], (size_t)h->plan.n_pt * 3, h->stream)) return -1;
@@ -1242,7 +1316,7 @@ int ba_get_dropped_pivots(ba_handle *h, int64_t *count, int reset) {
   HIP_TRY(hipMemcpyAsync(&v, h->ddev.bad_pivots, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (reset) HIP_TRY(hipMemsetAsync(h->ddev.bad_pivots, 0, sizeof(int), h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  *count = v;
+  *count = v % ba::kFlowTimeout;  // (the upper bits count timed-out hand-offs: ba_lm_sync reports those)
   return 0;
 }
 

@@ -186,6 +186,8 @@ struct DevProblem {
 };
 
 constexpr int kLinDump = 64 * 4 * 4;
+// added to DenseDev::bad_pivots by a dataflow sweep whose bounded poll gave up
+constexpr int kFlowTimeout = 1 << 20;
 constexpr int kBsChunks = 4;     // chunks per chunk-role workgroup of k_backsub_update
 constexpr int kCostGrid = 1792;  // 7 waves/SIMD resident on 256 CUs
 constexpr int kLmGrid = 1024;

@@ -253,26 +253,30 @@ OFFPATH = {
 }
 
 
-def config_scene(name, scale=1.0, pixel_sigma=0.0):
+def config_scene(name, scale=1.0, pixel_sigma=0.0, landmark_factor=1):
     """Scene of a BASELINE.json config; scale<1 shrinks poses and landmarks
     proportionally (parity-test sizes); pixel_sigma is the measurement noise in
-    pixels (0, and a second run at 0.5)."""
+    pixels (0, and a second run at 0.5); landmark_factor multiplies
+    landmarks and observations at FIXED poses (bench.py --weak: the per-GPU share
+    of the sharded work stays that of the one-GPU problem)."""
     if name == "C1":
+        if landmark_factor != 1:
+            raise ValueError("C1 is the fixed scene of test_ba.cpp: no landmark_factor")
         return test_ba_scene(pixel_sigma=pixel_sigma)
     if name in OFFPATH:
         kind, par = OFFPATH[name]
         if kind == "dense":
             n_pose, n_pt, views, seed = par
             return dense_covisibility_scene(max(20, int(round(n_pose * scale))),
-                                            max(200, int(round(n_pt * scale))), views, seed,
-                                            pixel_sigma=pixel_sigma)
+                                            max(200, int(round(n_pt * scale))) * landmark_factor,
+                                            views, seed, pixel_sigma=pixel_sigma)
         n_pose, n_pt, window, stereo, seed = par
         return synthetic_ba_scene(max(window + 6, int(round(n_pose * scale))),
-                                  max(16, int(round(n_pt * scale))), window, stereo, seed,
-                                  pixel_sigma=pixel_sigma)
+                                  max(16, int(round(n_pt * scale))) * landmark_factor, window,
+                                  stereo, seed, pixel_sigma=pixel_sigma)
     n_pose, n_pt, window, stereo, seed = CONFIGS[name]
     n_pose = max(window + 6, int(round(n_pose * scale)))
-    n_pt = max(16, int(round(n_pt * scale)))
+    n_pt = max(16, int(round(n_pt * scale))) * landmark_factor
     return synthetic_ba_scene(n_pose, n_pt, window, stereo, seed,
                               pixel_sigma=pixel_sigma)
 

@@ -61,7 +61,15 @@ class TorchExchange:
         self.stage_host = stage_host
         self.bufs = []
         self._streams = {}
-        for which in (0, 1):
+        if problem is not None:
+            self.attach(problem)
+
+    def attach(self, problem):
+        """Bind the three exchange buffers (reduced system, LM scalars, final
+        point gather) of a finalized problem and register the hook."""
+        torch = self.torch
+        self.bufs = []
+        for which in (0, 1, 2):
             n = problem.reduce_buffer_size(which)
             t = torch.zeros(n, dtype=torch.float64, device=self.device)
             problem.bind_reduce_buffer(which, t.data_ptr(), n)
@@ -93,3 +101,51 @@ class TorchExchange:
                 self.dist.all_reduce(buf)  # stream-ordered: RCCL waits on / is
                 #                            waited for by the current stream
         return 0
+
+
+class RcclExchange:
+    """The exchange over RCCL INSIDE the library (include/ba_hip.h, "RCCL
+    exchange"; csrc/ba_rccl.cpp): the hook is a C function, so no Python runs
+    between the kernels of an LM iteration.  torch.distributed (any backend) is
+    used once, to hand rank 0's communicator id to the other ranks.
+
+    Use torch's process group for barriers and host-side reductions; the
+    per-iteration collectives go through the library's own communicator."""
+
+    def __init__(self, problem, dist, rank, world, device_index):
+        import torch
+        self.lib = _lib.load()
+        if not self.lib.ba_rccl_available():
+            raise RuntimeError("RCCL exchange unavailable: %s" %
+                               (self.lib.ba_last_error() or b"?").decode())
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(self.lib.ba_rccl_get_unique_id(ident), "ba_rccl_get_unique_id")
+        if world > 1:
+            on_gpu = dist.get_backend() == "nccl"
+            t = torch.tensor(list(ident), dtype=torch.uint8,
+                             device=torch.device("cuda", device_index) if on_gpu else "cpu")
+            dist.broadcast(t, 0)
+            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        comm = C.c_void_p()
+        _lib.check(self.lib.ba_rccl_comm_create(C.byref(comm), rank, world, ident,
+                                                device_index), "ba_rccl_comm_create")
+        self.comm = comm
+        self.rank, self.world = rank, world
+        if problem is not None:
+            self.attach(problem)
+
+    def attach(self, problem):
+        problem.set_allreduce_native(self.lib.ba_rccl_allreduce_hook, self.comm.value)
+
+    def size(self):
+        """Ranks the communicator itself reports (ncclCommCount)."""
+        return int(_lib.check(self.lib.ba_rccl_comm_size(self.comm), "ba_rccl_comm_size"))
+
+    def calls(self):
+        return int(self.lib.ba_rccl_comm_calls(self.comm))
+
+    def close(self):
+        if self.comm:
+            self.lib.ba_rccl_comm_destroy(self.comm)
+            self.comm = None

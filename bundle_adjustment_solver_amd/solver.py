@@ -293,6 +293,19 @@ class BaProblem:
         self._keep.append(cb)
         check(self.lib.ba_set_allreduce(self.h, cb, None), "ba_set_allreduce")
 
+    def set_allreduce_native(self, fn_ptr, user_ptr):
+        """Register a C function (ba_allreduce_fn, e.g. ba_rccl_allreduce_hook)
+        with its user pointer: no Python inside the LM loop."""
+        fn = C.cast(fn_ptr, _lib.ALLREDUCE_FN)
+        self._keep.append(fn)
+        check(self.lib.ba_set_allreduce(self.h, fn, C.c_void_p(user_ptr)),
+              "ba_set_allreduce")
+
+    def gather_points(self):
+        """Final exchange of a sharded Solve (reference :1018-1022 writes back
+        every point): afterwards get_points() returns all points on every rank."""
+        check(self.lib.ba_gather_points(self.h), "ba_gather_points")
+
     def reduce_buffer_size(self, which):
         return int(self.lib.ba_reduce_buffer_size(self.h, which))
 
@@ -743,6 +756,9 @@ class FullBundleAdjustmentSolver:
 
     # ---- multi-GPU plumbing (new) ----
     def SetShard(self, rank, world, allreduce=None, stream=None):
+        """allreduce: a callable hook(which, dev_ptr, n_doubles, stream) -> int, or
+        an exchange object with .attach(problem) (sharding.TorchExchange /
+        sharding.RcclExchange built with problem=None)."""
         self._shard = (rank, world)
         self._allreduce = allreduce
         self._stream = stream
@@ -795,7 +811,10 @@ class FullBundleAdjustmentSolver:
             p.set_stream(self._stream)
         p.finalize()
         if self._allreduce is not None:
-            p.set_allreduce(self._allreduce)
+            if hasattr(self._allreduce, "attach"):   # an exchange object (sharding.py)
+                self._allreduce.attach(p)
+            else:                                    # hook(which, ptr, n, stream) -> int
+                p.set_allreduce(self._allreduce)
         self._problem = p
         self._connectivity_input = (pf, qf, opose, opt)
         self.num_optimization_poses_ = int((pf == 0).sum())
@@ -883,6 +902,10 @@ class FullBundleAdjustmentSolver:
                 obj[...] = T_wj[h]
             else:
                 obj[row] = T_wj[h]
+        if self._shard[1] > 1 and self._allreduce is not None:
+            # every rank writes back EVERY point (reference :1018-1022): one final
+            # sum-all-reduce of the owned rows
+            p.gather_points()
         X, owned = p.get_points()
         Xu = X * INVERSE_SCALER
         opt_mask = np.ones(self.num_total_points_, bool)

@@ -11,8 +11,13 @@
 // problem without the hook and requires bit-identical results: the exchange
 // path (packed S||rhs through ncclAllReduce on the solver's stream, separate
 // control kernel) must not change a single bit when there is nothing to add.
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -87,7 +92,129 @@ static void Register(Scene &s, FullBundleAdjustmentSolver &ba) {
   for (const Scene::Obs &o : s.obs) ba.AddObservation(o.cam, &s.poses[o.pose], &s.points[o.point], o.px);
 }
 
+// ---- "threads" mode: `world` shard facades on host threads of ONE process, all on
+// device 0 (what a one-GPU box can run with more than one shard).  The hook stages
+// the buffers through the host and meets the other shards at a barrier: the protocol
+// of the library (two exchanges per iteration + the final landmark gather) with a
+// real sum.  Every rank must write back EVERY pose and EVERY point (reference
+// core/full_bundle_adjustment_solver.cpp:1011-1022), identical on all ranks and
+// equal to the unsharded solve up to the permuted summation order.
+namespace {
+struct ThreadExchange {
+  int world = 1;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  std::vector<std::vector<double>> part;  // per rank
+  std::vector<double> sum;
+  void Barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const long g = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != g; });
+    }
+  }
+};
+struct ThreadRank {
+  ThreadExchange *x;
+  int rank;
+  long calls = 0;
+};
+int ThreadHook(void *user, int /*which*/, void *dev_ptr, int64_t n, void *stream) {
+  ThreadRank *r = static_cast<ThreadRank *>(user);
+  ThreadExchange &x = *r->x;
+  std::vector<double> &mine = x.part[r->rank];
+  mine.resize((size_t)n);
+  if (hipMemcpyAsync(mine.data(), dev_ptr, (size_t)n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return 1;
+  x.Barrier();
+  if (r->rank == 0) {
+    x.sum.assign((size_t)n, 0.0);
+    for (int k = 0; k < x.world; ++k)
+      for (int64_t e = 0; e < n; ++e) x.sum[e] += x.part[k][e];
+  }
+  x.Barrier();
+  if (hipMemcpyAsync(dev_ptr, x.sum.data(), (size_t)n * 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return 1;
+  x.Barrier();  // nobody overwrites `sum` before everyone has copied it
+  ++r->calls;
+  return 0;
+}
+
+int RunThreads(int world) {
+  Options options;
+  options.iteration_handle.max_num_iterations = 12;
+  options.convergence_handle.threshold_cost_change = 0.0f;
+  options.convergence_handle.threshold_step_size = 0.0f;
+  Scene plain_scene = MakeScene(40, 3000, 20240611u);
+  {
+    FullBundleAdjustmentSolver plain;
+    Register(plain_scene, plain);
+    plain.Solve(options, nullptr);
+  }
+  ThreadExchange x;
+  x.world = world;
+  x.part.resize(world);
+  std::vector<Scene> scenes;
+  for (int r = 0; r < world; ++r) scenes.push_back(MakeScene(40, 3000, 20240611u));
+  std::vector<ThreadRank> ranks(world);
+  std::vector<size_t> owned(world, 0);
+  std::vector<std::thread> th;
+  for (int r = 0; r < world; ++r) {
+    ranks[r].x = &x;
+    ranks[r].rank = r;
+    th.emplace_back([&, r] {
+      FullBundleAdjustmentSolver ba;
+      Register(scenes[r], ba);
+      ba.SetShard(r, world);
+      ba.SetAllReduce(&ThreadHook, &ranks[r]);
+      ba.Solve(options, nullptr);
+      for (const Point &p : scenes[r].points) owned[r] += ba.OwnsPoint(&p);
+    });
+  }
+  for (std::thread &t : th) t.join();
+  int fail = 0;
+  size_t owned_total = 0;
+  for (int r = 0; r < world; ++r) {
+    owned_total += owned[r];
+    if (ranks[r].calls != 2 * 12 + 2) {  // begin + 2 per iteration + the landmark gather
+      std::printf("rank %d: %ld hook calls, expected %d\n", r, ranks[r].calls, 2 * 12 + 2);
+      ++fail;
+    }
+    double dmax = 0, pmax = 0;
+    bool same_as_rank0 = true;
+    for (size_t q = 0; q < scenes[r].points.size(); ++q)
+      for (int c = 0; c < 3; ++c) {
+        dmax = std::max(dmax, std::fabs(scenes[r].points[q](c) - plain_scene.points[q](c)));
+        same_as_rank0 = same_as_rank0 && scenes[r].points[q](c) == scenes[0].points[q](c);
+      }
+    for (size_t j = 0; j < scenes[r].poses.size(); ++j)
+      for (int c = 0; c < 3; ++c) {
+        pmax = std::max(pmax, std::fabs(scenes[r].poses[j].translation()(c) - plain_scene.poses[j].translation()(c)));
+        same_as_rank0 = same_as_rank0 && scenes[r].poses[j].translation()(c) == scenes[0].poses[j].translation()(c);
+      }
+    std::printf("rank %d/%d: owns %zu landmarks; written-back points differ from the unsharded solve by %.2e m, poses by %.2e m; %s rank 0\n",
+                r, world, owned[r], dmax, pmax, same_as_rank0 ? "bit-identical to" : "DIFFERENT from");
+    if (!(dmax < 1e-7) || !(pmax < 1e-7) || !same_as_rank0) ++fail;
+  }
+  if (owned_total != plain_scene.points.size()) {
+    std::printf("the shards own %zu of %zu landmarks\n", owned_total, plain_scene.points.size());
+    ++fail;
+  }
+  std::printf(fail ? "THREAD SHARD TEST FAILED\n" : "THREAD SHARD TEST PASSED: every rank wrote back every point\n");
+  return fail ? 1 : 0;
+}
+}  // namespace
+
 int main(int argc, char **argv) {
+  if (argc == 3 && std::string(argv[1]) == "threads") return RunThreads(std::atoi(argv[2]));
   if (argc < 4) {
     std::fprintf(stderr, "usage: %s <rank> <world> <id_file> [device]\n", argv[0]);
     return 2;

@@ -89,9 +89,10 @@ class FullBundleAdjustmentSolver {
   // `world` (call before FinalizeParameters, with the SAME full problem
   // registered on every rank) and provides the sum-all-reduce the library calls
   // twice per LM iteration (ba_allreduce_fn of include/ba_hip.h; e.g.
-  // multi_gpu::RcclAllReduce::Hook of utility/rccl_allreduce.h).  After Solve
-  // every rank holds all poses; a rank's points are written back only for the
-  // landmarks it owns (OwnsPoint).
+  // multi_gpu::RcclAllReduce::Hook of utility/rccl_allreduce.h) and once more at
+  // the end of Solve for the landmarks (ba_gather_points).  After Solve every rank
+  // has written back all poses and ALL points (reference :1011-1022); OwnsPoint
+  // tells which landmarks this rank linearised (all of them without a hook).
   void SetShard(int rank, int world) {
     shard_rank_ = rank;
     shard_world_ = world;

@@ -1,9 +1,9 @@
 // Multi-GPU exchange for the C++ facade: the sum-all-reduce that
 // ba_set_allreduce (include/ba_hip.h) asks the caller to provide, implemented
-// over RCCL.  librccl.so is loaded with dlopen at run time, never linked: a
-// process that also holds PyTorch's bundled RCCL must not get a second copy
-// bound at link time, and machines without RCCL can still build and run the
-// single-GPU path.
+// over RCCL — the C++ face of the ba_rccl_* entry points of libba_hip.so
+// (include/ba_hip.h), which bind librccl.so with dlopen at run time, never at link
+// time: a process that also holds PyTorch's bundled RCCL must not get a second
+// copy, and machines without RCCL can still build and run the single-GPU path.
 //
 // One process per GPU.  Rank 0 creates the communicator id (NewUniqueId) and
 // hands its 128 bytes to the other ranks by any side channel (a file, an
@@ -12,7 +12,9 @@
 // RcclAllReduce::Hook / this through FullBundleAdjustmentSolver::SetAllReduce.
 // Per LM iteration the library calls the hook twice: the packed reduced camera
 // system S||rhs (1.5 MB at BASELINE config C4) and four LM scalars, both
-// in place, both ordered on the stream the kernels run on.
+// in place, both ordered on the stream the kernels run on; once more at the end
+// of Solve for the landmark rows (12 MB at C4), so that every rank writes back
+// every point.
 #ifndef BA_FACADE_RCCL_ALLREDUCE_H_
 #define BA_FACADE_RCCL_ALLREDUCE_H_
 
@@ -36,7 +38,8 @@ class RcclAllReduce {
 
   bool ok() const { return comm_ != nullptr; }
   const std::string &error() const { return error_; }
-  int64_t calls() const { return calls_; }
+  int64_t calls() const;  // all-reduces issued so far
+  int size() const;       // ranks the communicator itself sees (ncclCommCount)
 
   // ba_allreduce_fn (include/ba_hip.h): user = RcclAllReduce*
   static int Hook(void *user, int which, void *dev_ptr, int64_t n_doubles, void *hip_stream);
@@ -44,7 +47,6 @@ class RcclAllReduce {
  private:
   void *comm_ = nullptr;
   std::string error_;
-  int64_t calls_ = 0;
 };
 
 }  // namespace multi_gpu

@@ -300,8 +300,15 @@ bool FullBundleAdjustmentSolver::Solve(Options options, Summary *summary) {  // 
   // write back through the caller's pointers (:1011-1022)
   std::vector<double> T(12 * poses_.size()), X(3 * points_.size());
   Check(ba_get_poses(handle_, T.data()), "ba_get_poses");
+  // sharded: one final sum-all-reduce of the owned landmark rows, so that EVERY rank
+  // writes back EVERY point, as the reference's contract says (:1018-1022)
   owned_points_.assign(points_.size(), 1);
-  Check(ba_get_points(handle_, X.data(), owned_points_.data()), "ba_get_points");
+  Check(ba_get_points(handle_, X.data(), owned_points_.data()), "ba_get_points");  // (+ which landmarks are this shard's)
+  std::vector<uint8_t> valid(owned_points_);
+  if (shard_world_ > 1 && allreduce_fn_) {
+    Check(ba_gather_points(handle_), "ba_gather_points");
+    Check(ba_get_points(handle_, X.data(), valid.data()), "ba_get_points");
+  }
   for (size_t p = 0; p < poses_.size(); ++p) {
     if (fixed_poses_.count(static_cast<int>(p))) continue;
     _BA_Pose T_jw = Unpack12(&T[12 * p]);
@@ -310,7 +317,7 @@ bool FullBundleAdjustmentSolver::Solve(Options options, Summary *summary) {  // 
     *poses_[p] = T_jw.inverse();
   }
   for (size_t q = 0; q < points_.size(); ++q) {
-    if (fixed_points_.count(static_cast<int>(q)) || !owned_points_[q]) continue;
+    if (fixed_points_.count(static_cast<int>(q)) || !valid[q]) continue;
     X_[q] = _BA_Point(X[3 * q], X[3 * q + 1], X[3 * q + 2]);
     *points_[q] = X_[q] * inverse_scaler_;
   }

@@ -115,12 +115,43 @@ int ba_partition_points(int n_pose, const uint8_t *pose_fixed, int n_pt,
 typedef int (*ba_allreduce_fn)(void *user, int which, void *dev_ptr,
                                int64_t n_doubles, void *hip_stream);
 int ba_set_allreduce(ba_handle *h, ba_allreduce_fn fn, void *user);
-/* Size (in doubles) of exchange buffer `which`, valid after ba_finalize. */
+/* `which` = 2 (ba_gather_points only): every point of the FULL problem in user
+ * order, 3 doubles each, the rows of points this shard does not own zero. */
+/* Size (in doubles) of exchange buffer `which` (0, 1 or 2), valid after ba_finalize. */
 int64_t ba_reduce_buffer_size(ba_handle *h, int which);
 /* Use caller-allocated DEVICE memory for exchange buffer `which` (so that a
  * framework tensor can alias it).  Call after ba_finalize. */
 int ba_bind_reduce_buffer(ba_handle *h, int which, void *dev_ptr,
                           int64_t n_doubles);
+
+/* Write-back under sharding.  The reference updates EVERY registered, non-fixed
+ * point through the caller's pointer at the end of Solve (reference :1018-1022);
+ * a shard holds the final values of the landmarks it owns only.  This call
+ * sum-all-reduces the owned rows (hook, which = 2: 12 MB at BASELINE config C4,
+ * once per Solve); afterwards, and until the next ba_lm_begin / ba_lm_iterate /
+ * ba_stage_commit, ba_get_points returns every point of the full problem
+ * (owned_mask all 1) on every rank.  A no-op without a hook or with world = 1. */
+int ba_gather_points(ba_handle *h);
+
+/* ---- RCCL exchange (csrc/ba_rccl.cpp) ----------------------------------- */
+/* The hook above implemented over RCCL inside the library, so that no host
+ * language runs between the kernels of an LM iteration: rank 0 draws the 128-byte
+ * communicator id and hands it to the other ranks by any side channel (a file,
+ * MPI, a torch.distributed broadcast); every rank creates its communicator and
+ * registers  ba_set_allreduce(h, ba_rccl_allreduce_hook, comm).  librccl is
+ * bound with dlopen at the first call (BA_RCCL_LIB, else librccl.so.1 — the copy
+ * already in the process if a framework brought one). */
+typedef struct ba_rccl_comm ba_rccl_comm;
+int ba_rccl_available(void);                         /* 1 / 0 (reason: ba_last_error) */
+int ba_rccl_get_unique_id(uint8_t id128[128]);       /* ncclGetUniqueId */
+int ba_rccl_comm_create(ba_rccl_comm **out, int rank, int world,
+                        const uint8_t id128[128], int device_id);
+int ba_rccl_comm_size(ba_rccl_comm *c);              /* ranks the communicator sees (ncclCommCount) */
+int64_t ba_rccl_comm_calls(ba_rccl_comm *c);         /* all-reduces issued so far */
+void ba_rccl_comm_destroy(ba_rccl_comm *c);
+/* a ba_allreduce_fn; user = ba_rccl_comm* */
+int ba_rccl_allreduce_hook(void *user, int which, void *dev_ptr,
+                           int64_t n_doubles, void *hip_stream);
 
 /* ---- the LM loop ------------------------------------------------------- */
 /* Solve, reference :630-1044 (iteration loop :705-1008).  Runs until
@@ -133,6 +164,10 @@ int ba_solve(ba_handle *h, const ba_options *opt, ba_iter_info *out, int cap,
  * are device-side no-ops); sync = wait and read the iteration log. */
 int ba_lm_begin(ba_handle *h, const ba_options *opt);
 int ba_lm_iterate(ba_handle *h, int n);
+/* returns 1 when the loop has finished, 0 when not, < 0 on error — also when a
+ * dataflow hand-off of the reduced solve timed out on the device (the sweeps of
+ * csrc/ba_dense_tile.inc poll with a bound; x is then partly unsolved and every
+ * iteration since ba_lm_begin is invalid; ba_last_error names it). */
 int ba_lm_sync(ba_handle *h, ba_iter_info *out, int cap, int *n_iter,
                int *converged);
 
@@ -216,7 +251,8 @@ int ba_get_lin_info(ba_handle *h, int64_t out4[4]);
  * lambda at its floor) zeroes its column and solution component instead.
  * `count` receives how many such pivots the factorisations met since
  * ba_lm_begin (or since the last reset): 0 means the two factorisations agree
- * up to roundoff. */
+ * up to roundoff.  (Timed-out hand-offs of the dataflow sweeps are NOT counted
+ * here: they are errors, reported by ba_lm_sync.) */
 int ba_get_dropped_pivots(ba_handle *h, int64_t *count, int reset);
 
 /* ---- dense SPD solve alone (tests / micro-bench of the MFMA kernel) ---- */

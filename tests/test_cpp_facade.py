@@ -109,3 +109,17 @@ def test_cpp_rccl_allreduce_hook_world1_on_gpu(tmp_path):
     print(r.stdout)
     assert r.returncode == 0 and "MULTI GPU EXAMPLE PASSED" in r.stdout, r.stdout
     assert "bit-identical" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_two_shards_write_back_every_point_on_gpu():
+    """Write-back contract under sharding (reference core/full_bundle_adjustment_solver.cpp:
+    1011-1022: every registered pose and point is updated through the caller's pointer):
+    two shard facades on two host threads of one process (cpp/examples/multi_gpu_ba.cpp,
+    `threads` mode; the hook sums host-staged buffers at a barrier) must both end with
+    ALL points, bit-identical on the two ranks and equal to the unsharded solve."""
+    _ensure_built()
+    r = subprocess.run([os.path.join(CPP, "build", "multi_gpu_ba"), "threads", "2"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "THREAD SHARD TEST PASSED" in r.stdout, r.stdout

@@ -183,7 +183,7 @@ def test_two_shard_lm_loop_in_one_process(built):
     bufs = []
     for s_ in sh:
         per = []
-        for which in (0, 1):
+        for which in (0, 1, 2):
             n = s_.reduce_buffer_size(which)
             t = torch.zeros(n, dtype=torch.float64, device="cuda")
             s_.bind_reduce_buffer(which, t.data_ptr(), n)
@@ -211,11 +211,14 @@ def test_two_shard_lm_loop_in_one_process(built):
     for r in range(world):
         sh[r].set_allreduce(make_hook(r))
     out, errs = [None] * world, []
+    owned_X = [None] * world
 
     def run(rank):
         try:
             torch.cuda.set_device(0)
             out[rank] = sh[rank].solve(opt)
+            owned_X[rank] = sh[rank].get_points()
+            sh[rank].gather_points()       # the final exchange (which = 2)
         except Exception as e:  # noqa
             errs.append((rank, repr(e)))
             barrier.abort()
@@ -226,7 +229,7 @@ def test_two_shard_lm_loop_in_one_process(built):
     for t in th:
         t.join(timeout=300)
     assert not errs, errs
-    assert calls[0] == calls[1] >= 2 * n_it + 1
+    assert calls[0] == calls[1] >= 2 * n_it + 2
     for r in range(world):
         rows, _ = out[r]
         assert len(rows) == len(frows) == n_it
@@ -241,11 +244,21 @@ def test_two_shard_lm_loop_in_one_process(built):
     fX = full.get_points()[0]
     owned = np.zeros(fX.shape[0], bool)
     for r in range(world):
-        X, m = sh[r].get_points()
+        X, m = owned_X[r]
         assert not (owned & m).any()
         owned |= m
         assert relerr(X[m], fX[m]) < 1e-9
     assert owned.all()
+    # after ba_gather_points every shard holds EVERY point (the write-back contract of
+    # reference :1018-1022), bit-identical on both, and equal to its owner's values
+    G0, m0 = sh[0].get_points()
+    G1, m1 = sh[1].get_points()
+    assert m0.all() and m1.all()
+    assert np.array_equal(G0, G1)
+    for r in range(world):
+        X, m = owned_X[r]
+        assert np.array_equal(G0[m], X[m])
+    assert relerr(G0, fX) < 1e-9
 
 
 def _rank_worker(rank, world, port, q, null_stream=False):
@@ -271,14 +284,17 @@ def _rank_worker(rank, world, port, q, null_stream=False):
             ex = TorchExchange(p, dist, torch.device("cuda", 0), stage_host=True)
             rows, _ = p.solve(make_options(max_iter=12, thr_step=0, thr_cost=0))
             X, m = p.get_points()
+            p.gather_points()
+            G, gm = p.get_points()
+            assert gm.all()
             q.put((rank, "ok", [(r.iteration_status, r.damping_term, r.trial_cost, r.cost)
-                                for r in rows], p.get_poses(), X, m))
+                                for r in rows], p.get_poses(), X, m, G))
             del ex
         finally:
             dist.destroy_process_group()
     except Exception:  # noqa
         import traceback
-        q.put((rank, "FAIL: " + traceback.format_exc(), None, None, None, None))
+        q.put((rank, "FAIL: " + traceback.format_exc(), None, None, None, None, None))
 
 
 @pytest.mark.parametrize("null_stream", [False, True])
@@ -309,7 +325,7 @@ def test_two_rank_lm_loop_in_child_processes(null_stream, built):
         p.join(timeout=120)
     for rank, msg, *_ in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
-    for rank, _, rows, P, X, m in res:
+    for rank, _, rows, P, X, m, G in res:
         assert len(rows) == len(frows) == 12
         for k, ((st, lam, tc, c), b) in enumerate(zip(rows, frows)):
             assert st == b.iteration_status, (rank, k)
@@ -320,3 +336,49 @@ def test_two_rank_lm_loop_in_child_processes(null_stream, built):
         assert relerr(X[m], fX[m]) < 1e-9
     assert np.array_equal(res[0][3], res[1][3])        # identical replicated poses
     assert (res[0][5] ^ res[1][5]).all()               # owned masks partition the points
+    # after the final gather both ranks hold the full, identical point set
+    assert np.array_equal(res[0][6], res[1][6])
+    assert relerr(res[0][6], fX) < 1e-9
+
+
+def test_library_rccl_hook_world1_matches_plain_solve(built):
+    """The exchange bench.py uses for N > 1: RCCL called from C++ inside the
+    library (ba_rccl_allreduce_hook registered as a function pointer — no Python
+    between the kernels), the communicator id handed around by torch.distributed.
+    A one-GPU box can only form a one-rank communicator (RCCL refuses two ranks on
+    one device): the collectives are real, their sums trivial.  The sharded code path
+    of the library (ba_set_allreduce set: separate k_control, non-direct
+    k_schur_final + k_scatter, side stream) must reproduce the plain solve bit for
+    bit, the communicator must report one rank, and the hook must have been called
+    twice per iteration + once by ba_lm_begin."""
+    import torch
+    import torch.distributed as dist
+    from bundle_adjustment_solver_amd.sharding import RcclExchange
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29300 + os.getpid() % 500)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=29, pixel_sigma=0.3)
+        pr = scenes.scaled_problem(sc)
+        n_it = 10
+        opt = make_options(max_iter=n_it, thr_step=0, thr_cost=0)
+        plain = make(pr)
+        prows, _ = plain.solve(opt)
+        hooked = make(pr)
+        ex = RcclExchange(hooked, dist, 0, 1, 0)
+        assert ex.size() == 1
+        rows, _ = hooked.solve(opt)
+        assert ex.calls() == 2 * n_it + 1
+        assert len(rows) == len(prows) == n_it
+        for a, b in zip(rows, prows):
+            assert a.iteration_status == b.iteration_status
+            assert a.trial_cost == b.trial_cost and a.damping_term == b.damping_term
+        assert np.array_equal(hooked.get_poses(), plain.get_poses())
+        assert np.array_equal(hooked.get_points()[0], plain.get_points()[0])
+        hooked.gather_points()            # world 1: a no-op, the plain read-back stays
+        assert np.array_equal(hooked.get_points()[0], plain.get_points()[0])
+        hooked.close()
+        ex.close()
+    finally:
+        dist.destroy_process_group()
