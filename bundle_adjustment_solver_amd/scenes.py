@@ -281,6 +281,34 @@ def config_scene(name, scale=1.0, pixel_sigma=0.0, landmark_factor=1):
                               pixel_sigma=pixel_sigma)
 
 
+def pose_window_subscene(scene, p0, p1, n_fixed=5):
+    """The part of a window scene that lives on poses [p0, p1): those poses (the
+    first n_fixed of them fixed at their true values) and every landmark all of
+    whose observations fall inside; indices re-based.  Used to cut small test
+    problems out of a BASELINE config that keep a specific landmark's geometry."""
+    n_pt = scene["X_true"].shape[0]
+    first = np.full(n_pt, np.iinfo(np.int64).max)
+    last = np.full(n_pt, -1)
+    np.minimum.at(first, scene["obs_pt"], scene["obs_pose"])
+    np.maximum.at(last, scene["obs_pt"], scene["obs_pose"])
+    keep_pt = (first >= p0) & (last < p1)
+    new_index = np.cumsum(keep_pt) - 1
+    keep_obs = keep_pt[scene["obs_pt"]]
+    out = dict(
+        intr=scene["intr"], T_cj=scene["T_cj"],
+        T_wc_true=scene["T_wc_true"][p0:p1].copy(),
+        T_wc_init=scene["T_wc_init"][p0:p1].copy(),
+        X_true=scene["X_true"][keep_pt], X_init=scene["X_init"][keep_pt],
+        pose_fixed=np.arange(p1 - p0) < n_fixed,
+        pt_fixed=np.zeros(int(keep_pt.sum()), bool),
+        obs_cam=scene["obs_cam"][keep_obs],
+        obs_pose=(scene["obs_pose"][keep_obs] - p0).astype(np.int32),
+        obs_pt=new_index[scene["obs_pt"][keep_obs]].astype(np.int32),
+        obs_uv=scene["obs_uv"][keep_obs])
+    out["T_wc_init"][:n_fixed] = out["T_wc_true"][:n_fixed]
+    return out
+
+
 def scaled_problem(scene):
     """Apply the facade's host preprocessing (reference
     core/full_bundle_adjustment_solver.cpp:72-117,155-180): 0.01 scaling,

@@ -426,6 +426,11 @@ void ba_oracle::build_structure() {
 
 // Residual of one observation at the current parameters.
 // reference core/full_bundle_adjustment_solver.cpp:402-425 and :733-760.
+// The reference writes the projection in two ways that differ in the last bit:
+// the linearisation forms `fx * xinvz + cx` with xinvz = xj * invz (:753, :759),
+// EvaluateCurrentCost forms `fx * xj * invz + cx`, i.e. (fx * xj) * invz (:424).
+// COST selects the second form (ba_oracle_cost only).
+template <bool COST = false>
 static inline void project(const ba_oracle *o, int64_t k, double Xij[3],
                            double Xc[3], double r[2]) {
   const Cam &cam = o->cams[o->ocam[k]];
@@ -440,8 +445,13 @@ static inline void project(const ba_oracle *o, int64_t k, double Xij[3],
               cam.R[r0 * 3 + 2] * Xij[2]) +
              cam.t[r0];
   const double invz = 1.0 / Xc[2];
-  r[0] = cam.fx * (Xc[0] * invz) + cam.cx - o->ouv[2 * k + 0];
-  r[1] = cam.fy * (Xc[1] * invz) + cam.cy - o->ouv[2 * k + 1];
+  if (COST) {
+    r[0] = (cam.fx * Xc[0]) * invz + cam.cx - o->ouv[2 * k + 0];
+    r[1] = (cam.fy * Xc[1]) * invz + cam.cy - o->ouv[2 * k + 1];
+  } else {
+    r[0] = cam.fx * (Xc[0] * invz) + cam.cx - o->ouv[2 * k + 0];
+    r[1] = cam.fy * (Xc[1] * invz) + cam.cy - o->ouv[2 * k + 1];
+  }
 }
 
 extern "C" {
@@ -504,7 +514,7 @@ double ba_oracle_cost(ba_oracle *o) {
   double err = 0.0;
   for (int64_t k = 0; k < o->n_obs; ++k) {
     double Xij[3], Xc[3], r[2];
-    project(o, k, Xij, Xc, r);
+    project<true>(o, k, Xij, Xc, r);
     err += std::sqrt(r[0] * r[0] + r[1] * r[1]);
   }
   return err;

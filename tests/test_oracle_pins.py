@@ -395,3 +395,21 @@ def test_fast_solve_zero_pivot_gives_zero_step(built):
         xs.append(o.get_xy()[0].copy())
     assert (xs[0][-1] == 0).all() and (xs[1][-1] == 0).all()
     assert np.abs(xs[0] - xs[1]).max() <= 1e-9 * np.abs(xs[0]).max()
+
+
+def test_nan_cost_takes_the_skipped_branch_with_lambda_unchanged():
+    """Reference :930-953 with rho = NaN: `rho > 0.25` is false (revert, SKIPPED),
+    `rho > 0.5` and `rho <= 0.25` are both false (lambda unchanged); :1005 advances
+    previous_cost to the NaN trial cost.  (The regime bench.py's thresholds-off loop
+    ends in once a run-away landmark overflows; GPU twin:
+    tests/test_gpu_parity.py::test_nan_cost_branch_of_the_control_step_matches_oracle.)"""
+    sc = scenes.synthetic_ba_scene(12, 300, 5, True, seed=7)
+    pr = scenes.scaled_problem(sc)
+    pr["obs_uv"] = pr["obs_uv"].copy()
+    pr["obs_uv"][1234, 0] = np.nan
+    o = O.Oracle(pr)
+    rows, conv = o.solve(O.make_options(max_iter=5, thr_step=-1.0, thr_cost=-1.0))
+    assert len(rows) == 5 and not conv
+    for r in rows:
+        assert r.iteration_status == 2 and r.damping_term == 100.0
+        assert np.isnan(r.trial_cost) and np.isnan(r.rho)
