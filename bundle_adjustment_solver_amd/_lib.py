@@ -102,6 +102,18 @@ SIGNATURES = {
     "ba_rccl_comm_calls": (C.c_int64, [_P]),
     "ba_rccl_comm_destroy": (None, [_P]),
     "ba_rccl_allreduce_hook": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
+    "ba_stream_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int64]),
+    "ba_stream_destroy": (None, [_P]),
+    "ba_stream_set_cameras": (C.c_int, [_P, C.c_int, _D, _D]),
+    "ba_stream_set_poses": (C.c_int, [_P, C.c_int, _D, _U8]),
+    "ba_stream_set_points": (C.c_int, [_P, C.c_int, _D, _U8]),
+    "ba_stream_set_observations": (C.c_int, [_P, C.c_int64, _I32, _I32, _I32, _D]),
+    "ba_stream_finalize": (C.c_int, [_P]),
+    "ba_stream_solve": (C.c_int, [_P, C.POINTER(BaOptions), C.POINTER(BaIterInfo),
+                                  C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ba_stream_get_poses": (C.c_int, [_P, _D]),
+    "ba_stream_get_points": (C.c_int, [_P, _D]),
+    "ba_stream_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ba_solve": (C.c_int, [_P, C.POINTER(BaOptions), C.POINTER(BaIterInfo),
                            C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ba_lm_begin": (C.c_int, [_P, C.POINTER(BaOptions)]),

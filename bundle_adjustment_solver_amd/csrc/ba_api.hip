@@ -9,143 +9,17 @@
 #include <string>
 #include <vector>
 
-#include "../../include/ba_hip.h"
-#include "ba_dense_sched.h"
-#include "ba_device.h"
-#include "ba_plan.h"
-
-namespace ba {
-void launch_damp_invert_export(const DevProblem &d, hipStream_t s);
-void set_last_error(const std::string &m);  // (also used by ba_rccl.cpp)
-}
+#include "ba_handle.h"
 
 namespace {
-
 thread_local std::string g_err;
-
-int fail(const std::string &m) {
+}  // namespace
+void ba::set_last_error(const std::string &m) { g_err = m; }
+int ba::fail(const std::string &m) {
   g_err = m;
   return -1;
 }
-
-}  // namespace
-void ba::set_last_error(const std::string &m) { g_err = m; }
-namespace {
-
-#define HIP_TRY(expr)                                                        \
-  do {                                                                       \
-    hipError_t e_ = (expr);                                                  \
-    if (e_ != hipSuccess)                                                    \
-      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));        \
-  } while (0)
-
-enum Stage { ST_BUILD = 0, ST_SCHUR, ST_SOLVE, ST_BACKSUB, ST_COST, ST_CTRL, ST_XCHG, ST_N = 8 };
-
-}  // namespace
-
-struct ba_handle {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  // second stream for work that is independent inside one LM iteration
-  // (pose-side linearisation beside the landmark side + Schur accumulation;
-  // pose update beside the back-substitution), joined with events
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool overlap = true;
-  // the side stream holds work of the last enqueued iteration (pose-side
-  // linearisation at the trial point, reset of the factor tiles) that the main
-  // stream has not joined yet
-  bool side_pending = false;
-  // the factor tiles were reset by the last k_backsub_update (its tile-reset role): the
-  // next iteration needs no k_dense_init
-  bool tiles_ready = false;
-  // one LM iteration captured as a hipGraph (single GPU, no timing) and
-  // replayed by ba_lm_iterate instead of ~50 separate launches.  Opt-in
-  // (BA_GRAPH=1): on ROCm 7.2 / MI355X the replay measured 2.5 % SLOWER than
-  // plain launches on C4 (993 vs 969 us per iteration), see DESIGN.md.
-  bool use_graph = false;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  void drop_graph() {
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    graph_exec = nullptr;
-    graph = nullptr;
-  }
-  // host copies of the problem (scaled units)
-  int n_cam = 0, n_pose = 0, n_pt = 0;
-  int64_t n_obs = 0;
-  std::vector<double> cam_intr, cam_T, pose_T, pt_X, obs_uv;
-  std::vector<uint8_t> pose_fixed, pt_fixed;
-  std::vector<int32_t> obs_cam, obs_pose, obs_pt;
-  int rank = 0, world = 1;
-  bool finalized = false;
-  ba::Plan plan;
-  ba::DevProblem d;
-  std::vector<void *> allocs;
-  ba_allreduce_fn ar_fn = nullptr;
-  void *ar_user = nullptr;
-  int64_t xbuf_n[3] = {0, 0, 0};
-  // exchange buffer 2: every point of the full problem in user order (3 doubles each),
-  // rows of points this shard does not own zero — ba_gather_points
-  double *gbuf = nullptr;
-  bool gbuf_bound = false;
-  int32_t *pt_user_dev = nullptr;       // pt_user_of_int on the device (lazily)
-  std::vector<double> gathered;         // result of the last ba_gather_points (host, user order)
-  bool gathered_valid = false;
-  ba::DevCtrl hc;  // host mirror for the stage API
-  bool timing = false;
-  hipEvent_t ev[ST_N + 1];
-  bool ev_ok = false;
-  double stage_ms[ST_N] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool lm_begun = false;
-  ba::KernelTimer kt;        // per-kernel event timing (diagnostic mode)
-  ba::DenseSchedule sched;   // level schedule of the reduced-system Cholesky
-  ba::DenseDev ddev;
-  std::vector<int> pose_col_h;
-  // pose-only scratch (grown on demand, reused across calls)
-  // pose-only: one device buffer + its pinned host mirror (po_run), barrier scratch
-  uint8_t *po_dev = nullptr, *po_host = nullptr;
-  size_t po_cap = 0;
-  float *po_part = nullptr;
-
-  template <class T>
-  int dalloc(T **p, size_t n) {
-    *p = nullptr;
-    if (n == 0) n = 1;
-    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
-    if (e != hipSuccess)
-      return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
-    allocs.push_back((void *)*p);
-    return 0;
-  }
-  template <class T>
-  int upload(T **p, const std::vector<T> &v) {
-    if (dalloc(p, v.size())) return -1;
-    if (!v.empty()) {
-      hipError_t e = hipMemcpy(*p, v.data(), v.size() * sizeof(T),
-                               hipMemcpyHostToDevice);
-      if (e != hipSuccess)
-        return fail(std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
-    }
-    return 0;
-  }
-  void free_device() {
-    for (void *p : allocs) (void)hipFree(p);
-    allocs.clear();
-    if (po_dev) (void)hipFree(po_dev);
-    if (po_host) (void)hipHostFree(po_host);
-    po_dev = po_host = nullptr;
-    po_cap = 0;
-    po_part = nullptr;  // was in `allocs`
-    gbuf = nullptr;     // (its own: in `allocs`; bound: the caller's)
-    gbuf_bound = false;
-    pt_user_dev = nullptr;
-    gathered_valid = false;
-    finalized = false;
-  }
-};
+using ba::fail;
 
 namespace {
 
@@ -491,6 +365,12 @@ int ba_finalize(ba_handle *h) {
     std::memcpy(&cams[(size_t)c * 16], &h->cam_intr[(size_t)c * 4], 4 * sizeof(double));
     std::memcpy(&cams[(size_t)c * 16 + 4], &h->cam_T[(size_t)c * 12], 12 * sizeof(double));
   }
+  // Allocation kinds (ba_handle.h): with a device arena (ba_stream.hip) the arrays
+  // that scale with the landmark chunk live in it — structure / observations as
+  // kind 1 (restored only), blocks / points / partial sums as kind 2 (saved and
+  // restored); everything pose-sized stays resident (kind 0).  Without an arena
+  // every kind is a plain hipMalloc.
+  h->kind(0);
   if (h->upload(&d.cams, cams)) return -1;
   std::vector<double> poses((size_t)pl.n_pose * 12);
   for (int p = 0; p < pl.n_pose; ++p)
@@ -501,7 +381,9 @@ int ba_finalize(ba_handle *h) {
   for (int q = 0; q < pl.n_pt; ++q)
     std::memcpy(&pts[(size_t)q * 3], &h->pt_X[(size_t)pl.pt_user_of_int[q] * 3],
                 3 * sizeof(double));
+  h->kind(2);
   if (h->upload(&d.pts[0], pts) || h->upload(&d.pts[1], pts)) return -1;
+  h->kind(1);
 
   // structure
   static_assert(sizeof(int4) == 16 && sizeof(double2) == 16, "layout");
@@ -584,7 +466,9 @@ int ba_finalize(ba_handle *h) {
       HIP_TRY(hipMemcpy(d.chunk_desc, pl.chunk_desc.data(),
                         pl.chunk_desc.size() * sizeof(ba::Plan::ChunkDesc), hipMemcpyHostToDevice));
   }
+  h->kind(2);
   if (h->dalloc(&d.spart2, (size_t)d.n_slot * ba::kSlotStride)) return -1;
+  h->kind(1);
   {
     static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 64,
                   "group descriptor layout");
@@ -606,9 +490,11 @@ int ba_finalize(ba_handle *h) {
     if (h->dalloc(&d.lin_desc, pl.lin_desc.size())) return -1;
     if (d.n_lin_desc)
       HIP_TRY(hipMemcpy(d.lin_desc, pl.lin_desc.data(), pl.lin_desc.size() * sizeof(ba::Plan::LinDesc), hipMemcpyHostToDevice));
-    if (h->dalloc(&d.grp_pat, pl.grp_pat.size() / 2) || h->dalloc(&d.Apart2, (size_t)pl.n_apart2 * 27) || h->dalloc(&d.lin_dump, (size_t)ba::kLinDump) ||
-        h->upload(&d.pose_gpart_ptr, pl.pose_gpart_ptr) || h->upload(&d.pose_gpart, pl.pose_gpart))
+    if (h->dalloc(&d.grp_pat, pl.grp_pat.size() / 2) || h->upload(&d.pose_gpart_ptr, pl.pose_gpart_ptr) ||
+        h->upload(&d.pose_gpart, pl.pose_gpart))
       return -1;
+    h->kind(2);
+    if (h->dalloc(&d.Apart2, (size_t)pl.n_apart2 * 27) || h->dalloc(&d.lin_dump, (size_t)ba::kLinDump)) return -1;
     if (!pl.grp_pat.empty())
       HIP_TRY(hipMemcpy(d.grp_pat, pl.grp_pat.data(), pl.grp_pat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (pl.n_apart2 > 0) HIP_TRY(hipMemset(d.Apart2, 0, (size_t)pl.n_apart2 * 27 * sizeof(double)));
@@ -616,21 +502,27 @@ int ba_finalize(ba_handle *h) {
 
   // per-iteration storage
   for (int k = 0; k < 2; ++k) {
+    h->kind(2);
     if (h->dalloc(&d.Cu[k], (size_t)pl.M * 6) || h->dalloc(&d.b[k], (size_t)pl.M * 3) ||
-        h->dalloc(&d.W[k], std::max<size_t>(2, (size_t)pl.P * ba::kWStride)) || h->dalloc(&d.A[k], (size_t)pl.N * 36) ||
-        h->dalloc(&d.a[k], (size_t)pl.N * 6))
+        h->dalloc(&d.W[k], std::max<size_t>(2, (size_t)pl.P * ba::kWStride)))
       return -1;
+    h->kind(0);
+    if (h->dalloc(&d.A[k], (size_t)pl.N * 36) || h->dalloc(&d.a[k], (size_t)pl.N * 6)) return -1;
     HIP_TRY(hipMemset(d.W[k], 0, std::max<size_t>(1, (size_t)pl.P * ba::kWStride) * sizeof(double)));
     HIP_TRY(hipMemset(d.A[k], 0, std::max<size_t>(1, (size_t)pl.N * 36) * sizeof(double)));
     HIP_TRY(hipMemset(d.a[k], 0, std::max<size_t>(1, (size_t)pl.N * 6) * sizeof(double)));
   }
   d.n_obs_lm = pl.M > 0 ? pl.lm_obs_ptr[pl.M] : 0;
+  h->kind(2);
   if (h->dalloc(&d.Cd, (size_t)pl.M * 6) || h->dalloc(&d.Cinv, (size_t)pl.M * 6) ||
       h->dalloc(&d.lin_cost_part, (size_t)std::max(1, d.n_lin_cost)) ||
       h->dalloc(&d.Apart, (size_t)d.n_achunk * 27) ||
-      h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) || h->dalloc(&d.x, (size_t)pl.N * 6 + 64) ||
-      h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
-      h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_lm_part) * 2) || h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
+      h->dalloc(&d.spart, (size_t)d.n_tchunk * ba::kSlotStride) ||
+      h->dalloc(&d.y, (size_t)pl.M * 3) || h->dalloc(&d.lm_part, (size_t)std::max(1, d.n_lm_part) * 2))
+    return -1;
+  h->kind(0);
+  if (h->dalloc(&d.x, (size_t)pl.N * 6 + 64) || h->dalloc(&d.cost_part, (size_t)ba::kCostGrid) ||
+      h->dalloc(&d.pose_part, (size_t)2 + 2 * ba::kPoseGrid) ||
       h->dalloc(&d.scal, (size_t)4) || h->dalloc(&d.ctrl, (size_t)1))
     return -1;
   HIP_TRY(hipMemset(d.lin_cost_part, 0, (size_t)std::max(1, d.n_lin_cost) * sizeof(double)));
@@ -653,7 +545,27 @@ int ba_finalize(ba_handle *h) {
   // per level (row tiles per column, MFMA tile size) and run 1.1-1.9x faster at 64
   // (W20: 1.08 vs 1.21 ms per iteration, DENSE1K: 10.0 vs 19.0).  BA_DENSE_NB=32|64
   // forces one.
-  {
+  if (h->dense_owner) {
+    // streaming (ba_stream.hip): the reduced system is scattered, factorised and solved
+    // ONCE per iteration, by the owner; this handle aliases its dense image, schedule
+    // and solution (the S-block numbering and the tile schedule are global: identical
+    // on every landmark chunk) and keeps only its own packed partial S||rhs
+    const ba_handle *o = h->dense_owner;
+    if (!o->finalized || o->plan.N != pl.N || o->plan.B != pl.B)
+      return fail("ba_finalize: the dense owner belongs to a different problem");
+    h->sched = o->sched;
+    h->ddev = o->ddev;
+    h->pose_col_h = o->pose_col_h;
+    d.nb = o->d.nb; d.npad = o->d.npad; d.ld = o->d.ld;
+    d.L = o->d.L; d.Ldiag = o->d.Ldiag; d.pose_col = o->d.pose_col; d.col_x = o->d.col_x;
+    d.zt_I = o->d.zt_I; d.zt_J = o->d.zt_J; d.n_zt = o->d.n_zt;
+    d.x = o->d.x;
+    h->xbuf_n[0] = pl.B * 36 + 6 * (int64_t)pl.N;
+    h->xbuf_n[1] = 4;
+    h->xbuf_n[2] = 3 * (int64_t)pl.n_pt_global;
+    if (h->dalloc(&d.Spk, (size_t)h->xbuf_n[0])) return -1;
+    HIP_TRY(hipMemset(d.Spk, 0, (size_t)h->xbuf_n[0] * sizeof(double)));
+  } else {
     const char *nat = getenv("BA_DENSE_NATURAL");
     const char *full = getenv("BA_DENSE_FULL");
     const char *force = getenv("BA_DENSE_NB");
@@ -782,19 +694,24 @@ int ba_bind_reduce_buffer(ba_handle *h, int which, void *dev_ptr, int64_t n) {
 }
 
 // ---------------------------------------------------------------------------
-int ba_lm_begin(ba_handle *h, const ba_options *opt) {
-  if (!h || !opt) return fail("ba_lm_begin: bad argument");
-  if (!h->finalized && ba_finalize(h)) return -1;
-  if (use_device(h)) return -1;
+}  // extern "C"
+
+// Controller state for a new LM loop (reference :705-708): everything of
+// ba_lm_begin but the first linearisation.  *done_after = the loop is over before it
+// starts (max_num_iterations <= 0).  Shared with ba_stream.hip.
+int ba::lm_prepare_ctrl(ba_handle *h, const ba_options *opt, int *done_after) {
   if (opt->max_num_iterations > h->d.log_cap) {
     // grow the device-side iteration log
     ba::DevIterRec *nl = nullptr;
-    if (h->dalloc(&nl, (size_t)opt->max_num_iterations)) return -1;
+    const int keep = h->alloc_kind;
+    h->alloc_kind = 0;
+    const int rc = h->dalloc(&nl, (size_t)opt->max_num_iterations);
+    h->alloc_kind = keep;
+    if (rc) return -1;
     h->drop_graph();  // the captured kernels hold the old pointer
     h->d.log = nl;
     h->d.log_cap = opt->max_num_iterations;
   }
-  join_side(h);
   h->tiles_ready = false;
   h->gathered_valid = false;
   if (pull_ctrl(h)) return -1;  // keep `cur` and `lcur`
@@ -809,12 +726,25 @@ int ba_lm_begin(ba_handle *h, const ba_options *opt) {
   c.gn = opt->gauss_newton ? 1 : 0;
   c.iter = 0;
   c.converged = 0;
-  c.done = (opt->max_num_iterations <= 0) ? 1 : 0;
   c.prev_cost = 0.0;
-  const int done_after = c.done;
+  *done_after = (opt->max_num_iterations <= 0) ? 1 : 0;
   c.done = 0;
   if (push_ctrl(h)) return -1;
   HIP_TRY(hipMemsetAsync(h->ddev.bad_pivots, 0, sizeof(int), h->stream));
+  return 0;
+}
+int ba::ctrl_pull(ba_handle *h) { return pull_ctrl(h); }
+int ba::ctrl_push(ba_handle *h) { return push_ctrl(h); }
+
+extern "C" {
+
+int ba_lm_begin(ba_handle *h, const ba_options *opt) {
+  if (!h || !opt) return fail("ba_lm_begin: bad argument");
+  if (!h->finalized && ba_finalize(h)) return -1;
+  if (use_device(h)) return -1;
+  join_side(h);
+  int done_after = 0;
+  if (ba::lm_prepare_ctrl(h, opt, &done_after)) return -1;
   // first linearisation, at the starting point; previous_cost =
   // EvaluateCurrentCost() (reference :707) is the sum of its residual norms
   enqueue_linearize(h, 0);

@@ -322,9 +322,12 @@ __device__ __forceinline__ void ldlt3_inverse(const double c[6], double o[6]) {
 // backward stable for such a matrix: three reciprocals (v_rcp_f64 + two Newton
 // steps instead of IEEE divisions) and no pivot search / permutation selects — a
 // third of the instructions of the pivoted routine, which remains the fallback
-// whenever a pivot is not safely positive (relative to the largest diagonal entry):
-// the degenerate cases (never-observed landmark, rank-deficient C_i) keep Eigen's
-// pseudo-inverse semantics exactly.
+// whenever a pivot is not safely positive (below 1e-6 of the largest diagonal entry:
+// cond(C_i) > ~1e6): the degenerate cases (never-observed landmark, rank-deficient
+// C_i) keep Eigen's pseudo-inverse semantics exactly, and an ill-conditioned C_i — a
+// landmark whose depth is barely observable, the ones the LM loop lets run away once
+// lambda has fallen — is inverted with the reference's own pivot order (multipliers
+// <= 1: no overflow of the inverse where the unpivoted order has |l21| ~ 1e3).
 __device__ __forceinline__ double rcp_newton(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
@@ -333,7 +336,7 @@ __device__ __forceinline__ double rcp_newton(double d) {
 }
 __device__ __forceinline__ void spd3_inverse(const double c[6], double o[6]) {
   const double a00 = c[0], a01 = c[1], a02 = c[2], a11 = c[3], a12 = c[4], a22 = c[5];
-  const double thr = 1e-12 * fmax(a00, fmax(a11, a22));
+  const double thr = 1e-6 * fmax(a00, fmax(a11, a22));
   const double i0 = rcp_newton(a00);
   const double l10 = a01 * i0, l20 = a02 * i0;
   const double d1 = fma(-l10, a01, a11);

@@ -552,6 +552,89 @@ class BaProblem:
                     debug=dbg[:min(n_it.value, cap)] if want_debug else None)
 
 
+class BaStream:
+    """Observation streaming (include/ba_hip.h ba_stream_*): the
+    same problem-construction calls and LM loop as BaProblem for a problem whose
+    landmark-side data does not have to fit in device memory — n_chunks landmark
+    chunks pass through two device arenas of arena_bytes each, twice per iteration."""
+
+    def __init__(self, device=0, n_chunks=4, arena_bytes=1 << 30):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.ba_stream_create(C.byref(h), device, n_chunks, arena_bytes),
+              "ba_stream_create")
+        self.h = h
+        self.n_pose = self.n_pt = 0
+
+    def close(self):
+        if self.h:
+            self.lib.ba_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_cameras(self, intr4, T_cj12):
+        intr4 = np.ascontiguousarray(intr4, np.float64).reshape(-1, 4)
+        T = np.ascontiguousarray(T_cj12, np.float64).reshape(-1, 12)
+        check(self.lib.ba_stream_set_cameras(self.h, intr4.shape[0], _dp(intr4), _dp(T)),
+              "ba_stream_set_cameras")
+
+    def set_poses(self, T_jw12, fixed):
+        T = np.ascontiguousarray(T_jw12, np.float64).reshape(-1, 12)
+        f = np.ascontiguousarray(fixed, np.uint8)
+        self.n_pose = T.shape[0]
+        check(self.lib.ba_stream_set_poses(self.h, T.shape[0], _dp(T), _up(f)),
+              "ba_stream_set_poses")
+
+    def set_points(self, X3, fixed):
+        X = np.ascontiguousarray(X3, np.float64).reshape(-1, 3)
+        f = np.ascontiguousarray(fixed, np.uint8)
+        self.n_pt = X.shape[0]
+        check(self.lib.ba_stream_set_points(self.h, X.shape[0], _dp(X), _up(f)),
+              "ba_stream_set_points")
+
+    def set_observations(self, cam, pose, pt, uv):
+        cam = np.ascontiguousarray(cam, np.int32)
+        pose = np.ascontiguousarray(pose, np.int32)
+        pt = np.ascontiguousarray(pt, np.int32)
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        check(self.lib.ba_stream_set_observations(self.h, cam.shape[0], _ip(cam), _ip(pose),
+                                                  _ip(pt), _dp(uv)),
+              "ba_stream_set_observations")
+
+    def finalize(self):
+        check(self.lib.ba_stream_finalize(self.h), "ba_stream_finalize")
+
+    def solve(self, opt, cap=None):
+        cap = cap or max(1, opt.max_num_iterations)
+        rows = (BaIterInfo * cap)()
+        n = C.c_int(0)
+        conv = C.c_int(0)
+        check(self.lib.ba_stream_solve(self.h, C.byref(opt), rows, cap, C.byref(n),
+                                       C.byref(conv)), "ba_stream_solve")
+        return [rows[i] for i in range(min(n.value, cap))], bool(conv.value)
+
+    def get_poses(self):
+        out = np.zeros((self.n_pose, 12))
+        check(self.lib.ba_stream_get_poses(self.h, _dp(out)), "ba_stream_get_poses")
+        return out
+
+    def get_points(self):
+        out = np.zeros((self.n_pt, 3))
+        check(self.lib.ba_stream_get_points(self.h, _dp(out)), "ba_stream_get_points")
+        return out
+
+    def info(self):
+        v = (C.c_int64 * 6)()
+        check(self.lib.ba_stream_info(self.h, v), "ba_stream_info")
+        return dict(arena_bytes=v[0], largest_chunk_bytes=v[1], all_chunks_bytes=v[2],
+                    bytes_h2d=v[3], bytes_d2h=v[4], n_chunks=v[5])
+
+
 class FullBundleAdjustmentSolver:
     """Mirror of reference core/full_bundle_adjustment_solver.h:127-146.
 

@@ -255,6 +255,37 @@ int ba_get_lin_info(ba_handle *h, int64_t out4[4]);
  * here: they are errors, reported by ba_lm_sync.) */
 int ba_get_dropped_pivots(ba_handle *h, int64_t *count, int reset);
 
+/* ---- observation streaming: problems larger than device memory ---------- */
+/* SURVEY.md 8f N4 (the reference has no counterpart: its dense N x M grids stop it
+ * at 62 GB of host memory long before).  The landmarks are cut into n_chunks
+ * chunks by the rule of ba_set_shard; a chunk's observations, W = B_ji, C_i, b_i and
+ * points live in ONE of two device arenas of arena_bytes each and in a pinned host
+ * image otherwise; per LM iteration every chunk passes through the device twice
+ * (Schur accumulation; back-substitution + trial-point linearisation), its
+ * transfers overlapped with the kernels of the chunk before it.  Poses, the packed
+ * partial S||rhs and the controller are resident per chunk, the dense image and x
+ * once.  Same problem-construction calls, same options and iteration rows as
+ * ba_solve; the trajectory equals the resident solve up to the summation order of
+ * the chunks' partial sums.  ba_stream_finalize fails if a chunk does not fit the
+ * arena ("use more chunks"). */
+typedef struct ba_stream ba_stream;
+int ba_stream_create(ba_stream **out, int device_id, int n_chunks, int64_t arena_bytes);
+void ba_stream_destroy(ba_stream *s);
+int ba_stream_set_cameras(ba_stream *s, int n_cam, const double *intr4, const double *T_cj12);
+int ba_stream_set_poses(ba_stream *s, int n_pose, const double *T_jw12, const uint8_t *fixed);
+int ba_stream_set_points(ba_stream *s, int n_pt, const double *X3, const uint8_t *fixed);
+int ba_stream_set_observations(ba_stream *s, int64_t n_obs, const int32_t *cam, const int32_t *pose,
+                               const int32_t *point, const double *uv2);
+int ba_stream_finalize(ba_stream *s);
+int ba_stream_solve(ba_stream *s, const ba_options *opt, ba_iter_info *out, int cap,
+                    int *n_iter, int *converged);
+int ba_stream_get_poses(ba_stream *s, double *T_jw12);
+int ba_stream_get_points(ba_stream *s, double *X3);
+/* out6 = { device bytes of the arenas, bytes of the largest chunk, bytes of all
+ * chunks together (what a resident solve would hold), bytes copied host->device and
+ * device->host since ba_stream_finalize, number of chunks } */
+int ba_stream_info(ba_stream *s, int64_t out6[6]);
+
 /* ---- dense SPD solve alone (tests / micro-bench of the MFMA kernel) ---- */
 /* Solves A x = b for symmetric positive (semi-)definite A (n x n row-major
  * host arrays) with the blocked fp64-MFMA Cholesky used for the reduced
