@@ -89,6 +89,7 @@ SIGNATURES = {
     "ba_set_observations": (C.c_int, [_P, C.c_int64, _I32, _I32, _I32, _D]),
     "ba_set_shard": (C.c_int, [_P, C.c_int, C.c_int]),
     "ba_finalize": (C.c_int, [_P]),
+    "ba_update_values": (C.c_int, [_P, _D, _D]),
     "ba_partition_points": (C.c_int, [C.c_int, _U8, C.c_int, _U8, C.c_int64,
                                       _I32, _I32, C.c_int, _I32]),
     "ba_set_allreduce": (C.c_int, [_P, ALLREDUCE_FN, _P]),
@@ -111,6 +112,10 @@ SIGNATURES = {
     "ba_stream_finalize": (C.c_int, [_P]),
     "ba_stream_solve": (C.c_int, [_P, C.POINTER(BaOptions), C.POINTER(BaIterInfo),
                                   C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ba_stream_lm_begin": (C.c_int, [_P, C.POINTER(BaOptions)]),
+    "ba_stream_lm_iterate": (C.c_int, [_P, C.c_int]),
+    "ba_stream_lm_sync": (C.c_int, [_P, C.POINTER(BaIterInfo), C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ba_stream_get_poses": (C.c_int, [_P, _D]),
     "ba_stream_get_points": (C.c_int, [_P, _D]),
     "ba_stream_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -347,8 +348,18 @@ int ba_finalize(ba_handle *h) {
   in.obs_uv = h->obs_uv.data();
   in.rank = h->rank;
   in.world = h->world;
+  const bool times = getenv("BA_PLAN_TIMES") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!times) return;
+    (void)hipDeviceSynchronize();
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[finalize] %-26s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t_last).count());
+    t_last = n;
+  };
   std::string err = ba::build_plan(in, h->plan);
   if (!err.empty()) return fail("ba_finalize: " + err);
+  lap("host plan");
   const ba::Plan &pl = h->plan;
   ba::DevProblem &d = h->d;
   std::memset(&d, 0, sizeof(d));
@@ -411,9 +422,15 @@ int ba_finalize(ba_handle *h) {
   if (h->upload(&d.lm_obs_ptr, pl.lm_obs_ptr) || h->upload(&d.lm_pair_ptr, pl.lm_pair_ptr) ||
       h->upload(&d.pair_pose, pl.pair_pose) || h->upload(&d.pair_lm, pl.pair_lm) ||
       h->upload(&d.achunk_pose, pl.achunk_pose) || h->upload(&d.achunk_begin, pl.achunk_begin) ||
-      h->upload(&d.achunk_end, pl.achunk_end) || h->upload(&d.pose_achunk_ptr, pl.pose_achunk_ptr) ||
-      h->upload(&d.sblk_j, pl.sblk_j) || h->upload(&d.diag_blk, pl.diag_blk) ||
-      h->upload(&d.sblk_k, pl.sblk_k) || h->upload(&d.tri_p, pl.tri_p) ||
+      h->upload(&d.achunk_end, pl.achunk_end) || h->upload(&d.pose_achunk_ptr, pl.pose_achunk_ptr))
+    return -1;
+  // the block numbering of S is global (identical on every chunk) and k_scatter reads it
+  // when no particular chunk is resident: never in the arena
+  h->kind(0);
+  if (h->upload(&d.sblk_j, pl.sblk_j) || h->upload(&d.diag_blk, pl.diag_blk) || h->upload(&d.sblk_k, pl.sblk_k))
+    return -1;
+  h->kind(1);
+  if (h->upload(&d.tri_p, pl.tri_p) ||
       h->upload(&d.tri_q, pl.tri_q) || h->upload(&d.tchunk_blk, pl.tchunk_blk) ||
       h->upload(&d.tchunk_begin, pl.tchunk_begin) || h->upload(&d.tchunk_end, pl.tchunk_end) ||
       h->upload(&d.sblk_tchunk_ptr, pl.sblk_tchunk_ptr) ||
@@ -500,6 +517,7 @@ int ba_finalize(ba_handle *h) {
     if (pl.n_apart2 > 0) HIP_TRY(hipMemset(d.Apart2, 0, (size_t)pl.n_apart2 * 27 * sizeof(double)));
   }
 
+  lap("structure uploads");
   // per-iteration storage
   for (int k = 0; k < 2; ++k) {
     h->kind(2);
@@ -535,6 +553,7 @@ int ba_finalize(ba_handle *h) {
   d.log_cap = 4096;
   if (h->dalloc(&d.log, (size_t)d.log_cap)) return -1;
 
+  lap("block storage");
   // dense reduced system: tiles of 5 poses (32 columns) or 10 poses (64
   // columns), eliminated in the order of the level schedule.  Both schedules are
   // built.  NARROW patterns (every column tile has at most five row tiles below it
@@ -655,6 +674,7 @@ int ba_finalize(ba_handle *h) {
     HIP_TRY(hipMemset(d.Spk, 0, (size_t)h->xbuf_n[0] * sizeof(double)));
   }
 
+  lap("dense schedule + image");
   std::memset(&h->hc, 0, sizeof(h->hc));
   h->hc.lambda = 100.0;
   h->hc.huber = 1.0;
@@ -662,6 +682,36 @@ int ba_finalize(ba_handle *h) {
   HIP_TRY(hipMemcpy(d.ctrl, &h->hc, sizeof(ba::DevCtrl), hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
   h->finalized = true;
+  return 0;
+}
+
+int ba_update_values(ba_handle *h, const double *T_jw12, const double *X3) {
+  if (!h || !h->finalized) return fail("ba_update_values: not finalized");
+  if (h->arena) return fail("ba_update_values: not available on a streamed chunk");
+  if (use_device(h)) return -1;
+  const ba::Plan &pl = h->plan;
+  join_side(h);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (T_jw12) {
+    h->pose_T.assign(T_jw12, T_jw12 + 12 * (size_t)pl.n_pose);
+    std::vector<double> poses((size_t)pl.n_pose * 12);
+    for (int p = 0; p < pl.n_pose; ++p)
+      std::memcpy(&poses[(size_t)p * 12], T_jw12 + (size_t)pl.pose_user_of_int[p] * 12, 12 * sizeof(double));
+    for (int k = 0; k < 2; ++k)
+      HIP_TRY(hipMemcpy(h->d.poses[k], poses.data(), poses.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (X3) {
+    h->pt_X.assign(X3, X3 + 3 * (size_t)pl.n_pt_global);
+    std::vector<double> pts((size_t)pl.n_pt * 3);
+    for (int q = 0; q < pl.n_pt; ++q)
+      std::memcpy(&pts[(size_t)q * 3], X3 + (size_t)pl.pt_user_of_int[q] * 3, 3 * sizeof(double));
+    if (pl.n_pt > 0)
+      for (int k = 0; k < 2; ++k)
+        HIP_TRY(hipMemcpy(h->d.pts[k], pts.data(), pts.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  h->gathered_valid = false;
+  h->lm_begun = false;   // the blocks on the device belong to the old values: ba_lm_begin linearises again
+  h->tiles_ready = false;
   return 0;
 }
 

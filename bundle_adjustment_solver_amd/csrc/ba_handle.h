@@ -139,8 +139,8 @@ struct ba_handle {
     allocs.push_back((void *)*p);
     return 0;
   }
-  template <class T>
-  int upload(T **p, const std::vector<T> &v) {
+  template <class T, class A>
+  int upload(T **p, const std::vector<T, A> &v) {
     if (dalloc(p, v.size())) return -1;
     if (!v.empty()) {
       hipError_t e = hipMemcpy(*p, v.data(), v.size() * sizeof(T),

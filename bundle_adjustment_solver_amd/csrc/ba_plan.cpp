@@ -4,13 +4,52 @@
 #include "ba_dense_sched.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 
 namespace ba {
 
 namespace {
+
+// BA_PLAN_TIMES=1: wall time of the planner's phases on stderr (developer knob)
+struct PhaseClock {
+  const bool on = getenv("BA_PLAN_TIMES") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[plan] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
+// Static-chunk parallel loop over [0, n) on host threads (BA_PLAN_THREADS, default:
+// the hardware's, at most 16).  Every use below writes disjoint outputs per index
+// and all prefix sums stay sequential, so the plan is identical for every thread
+// count (tests/cpp/plan_check.cpp compares it with the one-thread build).
+int plan_threads() {
+  static const int n = [] {
+    const char *e = getenv("BA_PLAN_THREADS");
+    int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(v, 16));
+  }();
+  return n;
+}
+template <class F>
+void parallel_for(int64_t n, const F &fn) {
+  const int nt = (int)std::min<int64_t>(plan_threads(), std::max<int64_t>(1, n / 4096));
+  if (nt <= 1) {
+    fn((int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+  for (auto &x : th) x.join();
+}
 
 // Internal pose order: optimised poses in input order, then fixed poses.
 void order_poses(const PlanInput &in, std::vector<int32_t> &int_of_user,
@@ -188,6 +227,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     if (in.obs_pt[k] < 0 || in.obs_pt[k] >= in.n_pt)
       return "observation with invalid point index";
   }
+  PhaseClock clk;
   pl = Plan();
   pl.n_cam = in.n_cam;
   pl.n_pose = in.n_pose;
@@ -217,6 +257,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     }
   }
   pl.M = (int)pl.pt_user_of_int.size();
+  clk.lap("validate + order + owners");
   // ---- covisibility groups: landmarks with the identical OBSERVATION PATTERN —
   // the same sequence of (pose, camera) over their observations in landmark-major
   // order, fixed poses included — hence the identical set of optimisable poses
@@ -227,29 +268,71 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   // gathers, no index records, pose side in the same pass); k_schur_grp turns its
   // Schur contributions into one dense product.  Everything else keeps the
   // locality order and goes through the chunk / super-run kernels. ----
+  // ---- observations of the OWNED points as a CSR over user point ids, every list in
+  // (pose, insertion) order: built once, used by the covisibility grouping below and,
+  // landmark by landmark in the final order, by the landmark-major list ----
+  std::vector<int64_t> uo_ptr((size_t)in.n_pt + 1, 0);
+  for (int64_t k = 0; k < in.n_obs; ++k)
+    if (pl.owner[in.obs_pt[k]] == in.rank) uo_ptr[in.obs_pt[k] + 1]++;
+  for (int q = 0; q < in.n_pt; ++q) uo_ptr[q + 1] += uo_ptr[q];
+  // (packed records: every later pass reads a landmark's observations as ONE contiguous
+  //  run instead of gathering four input arrays at random positions)
+  struct ObsRecP {
+    int32_t pose, cam;  // internal pose index, camera
+    double u, v;
+  };
+  pvec<ObsRecP> uo_rec((size_t)uo_ptr[in.n_pt]);
+  {
+    std::vector<int64_t> cur(uo_ptr.begin(), uo_ptr.end() - 1);
+    for (int64_t k = 0; k < in.n_obs; ++k) {
+      const int q = in.obs_pt[k];
+      if (pl.owner[q] != in.rank) continue;
+      ObsRecP &r = uo_rec[cur[q]++];
+      r.pose = pl.pose_int_of_user[in.obs_pose[k]];
+      r.cam = in.obs_cam[k];
+      r.u = in.obs_uv ? in.obs_uv[2 * k + 0] : 0.0;
+      r.v = in.obs_uv ? in.obs_uv[2 * k + 1] : 0.0;
+    }
+  }
+  parallel_for(in.n_pt, [&](int64_t q0, int64_t q1) {
+    for (int64_t q = q0; q < q1; ++q) {
+      // stable insertion sort by pose (lists are short and nearly sorted: the usual
+      // insertion order is pose-major)
+      ObsRecP *a = uo_rec.data() + uo_ptr[q];
+      const int64_t n = uo_ptr[q + 1] - uo_ptr[q];
+      for (int64_t i = 1; i < n; ++i) {
+        if (a[i - 1].pose <= a[i].pose) continue;
+        const ObsRecP x = a[i];
+        int64_t j = i;
+        while (j > 0 && a[j - 1].pose > x.pose) {
+          a[j] = a[j - 1];
+          --j;
+        }
+        a[j] = x;
+      }
+    }
+  });
+  clk.lap("per-point observation lists");
   pl.M_grp = 0;
   pl.grp_range.clear();
   pl.lin_groups = !(getenv("BA_NO_LINGRP") && getenv("BA_NO_LINGRP")[0] == '1');
+  if (pl.n_cam >= 65536) pl.lin_groups = false;  // (the pattern record packs the camera into 16 bits)
   if (pl.M > 0 && !(getenv("BA_NO_GROUPS") && getenv("BA_NO_GROUPS")[0] == '1')) {
     const int M0 = pl.M;
     std::vector<int64_t> kp(M0 + 1, 0);
-    for (int64_t k = 0; k < in.n_obs; ++k) {
-      const int32_t pi = pl.pt_int_of_user[in.obs_pt[k]];
-      if (pi >= 0) kp[pi + 1]++;
+    for (int i = 0; i < M0; ++i) {
+      const int q = pl.pt_user_of_int[i];
+      kp[i + 1] = kp[i] + (uo_ptr[q + 1] - uo_ptr[q]);
     }
-    for (int i = 0; i < M0; ++i) kp[i + 1] += kp[i];
     std::vector<uint64_t> pat((size_t)kp[M0]);  // (pose << 32) | camera, per point in (pose, insertion) order
-    {
-      std::vector<int64_t> cur(kp.begin(), kp.end() - 1);
-      for (int64_t k = 0; k < in.n_obs; ++k) {
-        const int32_t pi = pl.pt_int_of_user[in.obs_pt[k]];
-        if (pi >= 0)
-          pat[cur[pi]++] = ((uint64_t)(uint32_t)pl.pose_int_of_user[in.obs_pose[k]] << 32) | (uint32_t)in.obs_cam[k];
+    parallel_for(M0, [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; ++i) {
+        const int q = pl.pt_user_of_int[i];
+        int64_t w = kp[i];
+        for (int64_t t = uo_ptr[q]; t < uo_ptr[q + 1]; ++t)
+          pat[w++] = ((uint64_t)(uint32_t)uo_rec[t].pose << 32) | (uint32_t)uo_rec[t].cam;
       }
-      for (int i = 0; i < M0; ++i)
-        std::stable_sort(pat.begin() + kp[i], pat.begin() + kp[i + 1],
-                         [](uint64_t x, uint64_t y) { return (x >> 32) < (y >> 32); });
-    }
+    });
     auto deg = [&](int i) { return (int)(kp[i + 1] - kp[i]); };
     auto dopt = [&](int i) {  // distinct optimisable poses
       int n = 0;
@@ -279,7 +362,29 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       //  back-substituted: groups of them keep those kernels' chunk launches empty)
       if (dop[i] <= kGrpMaxPoses && deg(i) >= 1 && deg(i) <= kGrpMaxObs) cand.push_back(i);
     }
-    std::stable_sort(cand.begin(), cand.end(), less_sig);  // stable: locality order inside a group
+    // stable sort by pattern (stable: locality order inside a group).  The candidates
+    // arrive in locality order, i.e. already grouped by their first observing pose = the
+    // first pattern word's pose: every run of equal first pose is sorted on its own, the
+    // runs in parallel (the result is the stable sort of the whole list whenever the
+    // first poses are non-decreasing, which the check below establishes).
+    {
+      std::vector<size_t> run0(1, 0);
+      bool monotone = true;
+      for (size_t t = 1; t < cand.size(); ++t) {
+        const uint64_t a0 = pat[kp[cand[t - 1]]] >> 32, b0 = pat[kp[cand[t]]] >> 32;
+        if (b0 < a0) monotone = false;
+        if (b0 != a0) run0.push_back(t);
+      }
+      run0.push_back(cand.size());
+      if (!monotone) {
+        std::stable_sort(cand.begin(), cand.end(), less_sig);
+      } else {
+        parallel_for((int64_t)run0.size() - 1, [&](int64_t r0, int64_t r1) {
+          for (int64_t r = r0; r < r1; ++r)
+            std::stable_sort(cand.begin() + run0[r], cand.begin() + run0[r + 1], less_sig);
+        });
+      }
+    }
     std::vector<uint8_t> grouped(M0, 0);
     std::vector<int32_t> neworder;
     neworder.reserve(M0);
@@ -308,6 +413,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     for (int k = 0; k < M0; ++k) pl.pt_int_of_user[pl.pt_user_of_int[k]] = k;
   }
   if (pl.M_grp == 0) pl.lin_groups = false;
+  clk.lap("covisibility groups");
   // Interleave inside windows of one Schur super-run: position p of a window
   // takes the landmark p would have had in residue-class order (k = r, r + S,
   // r + 2S, ...), so that every chunk of consecutive landmarks samples the
@@ -335,59 +441,77 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   pl.n_pt = (int)pl.pt_user_of_int.size();
   const int M = pl.M;
 
+  clk.lap("interleave + fixed points");
   // ---- landmark-major observation list ----
-  std::vector<int64_t> sel;
-  sel.reserve(in.n_obs / in.world + 16);
-  for (int64_t k = 0; k < in.n_obs; ++k)
-    if (pl.pt_int_of_user[in.obs_pt[k]] >= 0) sel.push_back(k);
-  pl.n_obs = (int64_t)sel.size();
-  auto key_lm = [&](int64_t k) -> uint64_t {
-    return ((uint64_t)(uint32_t)pl.pt_int_of_user[in.obs_pt[k]] << 32) |
-           (uint32_t)pl.pose_int_of_user[in.obs_pose[k]];
-  };
+  // = the per-point lists in the final landmark order (key: landmark, pose, insertion).
+  // Per landmark: its observations and its (landmark, pose) pairs — one per distinct
+  // optimisable pose, carried by the LAST inserted observation of that pose (reference
+  // :826: B_ji is assigned, not accumulated).  Counts first, prefix sums, then every
+  // landmark fills its own ranges: parallel over landmarks.
   {
-    std::vector<uint64_t> keys(sel.size());
-    for (size_t s = 0; s < sel.size(); ++s) keys[s] = key_lm(sel[s]);
-    std::vector<int64_t> perm(sel.size());
-    std::iota(perm.begin(), perm.end(), (int64_t)0);
-    std::stable_sort(perm.begin(), perm.end(),
-                     [&](int64_t a, int64_t b) { return keys[a] < keys[b]; });
-    std::vector<int64_t> sorted(sel.size());
-    for (size_t s = 0; s < sel.size(); ++s) sorted[s] = sel[perm[s]];
-    sel.swap(sorted);
-  }
-  pl.obs_idx.resize((size_t)pl.n_obs * 4);
-  pl.obs_uv.resize((size_t)pl.n_obs * 2);
-  pl.lm_obs_ptr.assign(M + 1, 0);
-  pl.lm_pair_ptr.assign(M + 1, 0);
-  pl.pair_pose.clear();
-  pl.pair_lm.clear();
-  for (int64_t s = 0; s < pl.n_obs; ++s) {
-    const int64_t k = sel[s];
-    const int32_t pi = pl.pt_int_of_user[in.obs_pt[k]];
-    const int32_t ji = pl.pose_int_of_user[in.obs_pose[k]];
-    pl.obs_idx[4 * s + 0] = in.obs_cam[k];
-    pl.obs_idx[4 * s + 1] = ji;
-    pl.obs_idx[4 * s + 2] = pi;
-    pl.obs_idx[4 * s + 3] = -1;
-    pl.obs_uv[2 * s + 0] = in.obs_uv[2 * k + 0];
-    pl.obs_uv[2 * s + 1] = in.obs_uv[2 * k + 1];
-    if (pi < M) {
-      pl.lm_obs_ptr[pi + 1]++;
-      if (ji < N) {
-        const bool is_new = pl.pair_pose.empty() || pl.pair_lm.back() != pi ||
-                            pl.pair_pose.back() != ji;
-        if (is_new) {
-          pl.pair_pose.push_back(ji);
-          pl.pair_lm.push_back(pi);
-          pl.lm_pair_ptr[pi + 1]++;
-        } else {
-          // same pair as the previous (adjacent) observation: the earlier
-          // insertion loses its B_ji to this one (reference :826)
-          pl.obs_idx[4 * (s - 1) + 3] = -1;
+    const int n_own = pl.n_pt;
+    std::vector<int64_t> optr((size_t)n_own + 1, 0), pptr((size_t)n_own + 1, 0);
+    parallel_for(n_own, [&](int64_t a0, int64_t a1) {
+      for (int64_t pi = a0; pi < a1; ++pi) {
+        const int q = pl.pt_user_of_int[pi];
+        optr[pi + 1] = uo_ptr[q + 1] - uo_ptr[q];
+        if (pi < M) {
+          int64_t np = 0;
+          int32_t last = -1;
+          for (int64_t t = uo_ptr[q]; t < uo_ptr[q + 1]; ++t) {
+            const int32_t ji = uo_rec[t].pose;
+            if (ji < N && ji != last) ++np;
+            last = ji;
+          }
+          pptr[pi + 1] = np;
         }
-        pl.obs_idx[4 * s + 3] = (int32_t)(pl.pair_pose.size() - 1);
       }
+    });
+    for (int pi = 0; pi < n_own; ++pi) {
+      optr[pi + 1] += optr[pi];
+      pptr[pi + 1] += pptr[pi];
+    }
+    pl.n_obs = optr[n_own];
+    if (pptr[n_own] >= (int64_t)INT32_MAX) return "too many pairs for int32 pair ids";
+    pl.obs_idx.resize((size_t)pl.n_obs * 4);
+    pl.obs_uv.resize((size_t)pl.n_obs * 2);
+    pl.lm_obs_ptr.assign(M + 1, 0);
+    pl.lm_pair_ptr.assign(M + 1, 0);
+    pl.pair_pose.resize((size_t)pptr[n_own]);
+    pl.pair_lm.resize((size_t)pptr[n_own]);
+    parallel_for(n_own, [&](int64_t a0, int64_t a1) {
+      for (int64_t pi = a0; pi < a1; ++pi) {
+        const int q = pl.pt_user_of_int[pi];
+        int64_t s = optr[pi], pw = pptr[pi] - 1;
+        int32_t last = -1;
+        for (int64_t t = uo_ptr[q]; t < uo_ptr[q + 1]; ++t, ++s) {
+          const ObsRecP &r = uo_rec[t];
+          const int32_t ji = r.pose;
+          pl.obs_idx[4 * s + 0] = r.cam;
+          pl.obs_idx[4 * s + 1] = ji;
+          pl.obs_idx[4 * s + 2] = (int32_t)pi;
+          pl.obs_idx[4 * s + 3] = -1;
+          pl.obs_uv[2 * s + 0] = r.u;
+          pl.obs_uv[2 * s + 1] = r.v;
+          if (pi < M && ji < N) {
+            if (ji != last) {
+              ++pw;
+              pl.pair_pose[pw] = ji;
+              pl.pair_lm[pw] = (int32_t)pi;
+            } else {
+              // same pair as the previous (adjacent) observation: the earlier
+              // insertion loses its B_ji to this one (reference :826)
+              pl.obs_idx[4 * (s - 1) + 3] = -1;
+            }
+            pl.obs_idx[4 * s + 3] = (int32_t)pw;
+          }
+          last = (pi < M && ji < N) ? ji : -1;
+        }
+      }
+    });
+    for (int i = 0; i < M; ++i) {
+      pl.lm_obs_ptr[i + 1] = optr[i + 1] - optr[i];
+      pl.lm_pair_ptr[i + 1] = pptr[i + 1] - pptr[i];
     }
   }
   for (int i = 0; i < M; ++i) {
@@ -396,8 +520,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   }
   pl.n_obs_opt = pl.lm_obs_ptr[M];
   pl.P = (int64_t)pl.pair_pose.size();
-  if (pl.P >= (int64_t)INT32_MAX) return "too many pairs for int32 pair ids";
 
+  clk.lap("landmark-major list");
   // ---- pose-major observation list (optimisable poses) ----
   {
     std::vector<int64_t> psel;
@@ -431,6 +555,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
                 pl.achunk_begin, pl.achunk_end, pl.pose_achunk_ptr);
   }
 
+  clk.lap("pose-major list");
   // ---- Schur complement structure ----
   // Non-zero upper blocks (j <= k) of S = union over landmarks of J(i) x J(i),
   // plus every diagonal.  Landmarks are processed LANDMARK-MAJOR by "Schur
@@ -446,7 +571,16 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     std::vector<std::vector<int32_t>> rowk(N);
     for (int j = 0; j < N; ++j) rowk[j].push_back(j);
     if (in.world == 1) {
-      for (int i = 0; i < M; ++i)
+      // (the landmarks of a covisibility group share one pose set: its first landmark
+      //  stands for all of them)
+      auto add_landmark = [&](int i) {
+        for (int64_t p = pl.lm_pair_ptr[i]; p < pl.lm_pair_ptr[i + 1]; ++p) {
+          auto &rk = rowk[pl.pair_pose[p]];
+          for (int64_t q = p; q < pl.lm_pair_ptr[i + 1]; ++q) rk.push_back(pl.pair_pose[q]);
+        }
+      };
+      for (const Plan::GrpRange &gr : pl.grp_range) add_landmark(gr.l0);
+      for (int i = pl.M_grp; i < M; ++i)
         for (int64_t p = pl.lm_pair_ptr[i]; p < pl.lm_pair_ptr[i + 1]; ++p) {
           auto &rk = rowk[pl.pair_pose[p]];
           for (int64_t q = p; q < pl.lm_pair_ptr[i + 1]; ++q) {
@@ -859,6 +993,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     }
   }
 
+  clk.lap("Schur structure");
   // ---- back-substitution chunks: consecutive landmarks, <= kSchurPairs pairs
   // (a landmark with more pairs forms a chunk of its own) ----
   {
@@ -899,6 +1034,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     for (auto &g : pl.lin_desc)
       for (int t = 0; t < g.d; ++t) pl.pose_gpart[cur[pl.pair_pose[g.p0 + t]]++] = g.apart0 + t;
   }
+  clk.lap("chunks + bookkeeping");
 
   return std::string();
 }

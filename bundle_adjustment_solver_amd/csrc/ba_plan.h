@@ -13,10 +13,34 @@
 #define BA_PLAN_H_
 
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace ba {
+
+// std::vector whose resize() leaves trivially constructible elements uninitialised:
+// the planner's big arrays (observation lists: 200 MB at BASELINE config C4) are
+// written exactly once, by parallel loops — a zero fill in front of that would touch
+// every page a first time on ONE thread.
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = default_init_allocator<U>;
+  };
+  using std::allocator<T>::allocator;
+  template <class U, class... Args>
+  void construct(U *p, Args &&...args) {
+    if constexpr (sizeof...(Args) == 0)
+      ::new ((void *)p) U;
+    else
+      ::new ((void *)p) U(std::forward<Args>(args)...);
+  }
+};
+template <class T>
+using pvec = std::vector<T, default_init_allocator<T>>;
 
 struct PlanInput {
   int n_cam = 0;
@@ -85,13 +109,13 @@ struct Plan {
   std::vector<int32_t> owner;          // n_pt_global owner rank
 
   // ---- landmark-major observations ----
-  std::vector<int32_t> obs_idx;   // n_obs*4: cam, pose_int, pt_int, pair|-1
-  std::vector<double> obs_uv;     // n_obs*2
+  pvec<int32_t> obs_idx;          // n_obs*4: cam, pose_int, pt_int, pair|-1
+  pvec<double> obs_uv;            // n_obs*2
   std::vector<int64_t> lm_obs_ptr;   // M+1
   // ---- pairs ----
   std::vector<int64_t> lm_pair_ptr;  // M+1
-  std::vector<int32_t> pair_pose;    // P (internal pose, < N)
-  std::vector<int32_t> pair_lm;      // P (internal point, < M)
+  pvec<int32_t> pair_pose;           // P (internal pose, < N)
+  pvec<int32_t> pair_lm;             // P (internal point, < M)
   // ---- pose-major observations (optimisable poses only) ----
   std::vector<int32_t> pobs_idx;  // n_pobs*2: cam, pt_int (pose-major copy: the pose is implied)
   std::vector<double> pobs_uv;    // n_pobs*2

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,7 +49,7 @@ struct ba_stream {
   std::vector<uint8_t> in_pending, dirty, computed;
   int resident[2] = {-1, -1};
   double *scal_sum = nullptr;
-  bool finalized = false;
+  bool finalized = false, lm_begun = false;
   int64_t bytes_h2d = 0, bytes_d2h = 0;
   // problem (host, until finalize)
   int n_cam = 0, n_pose = 0, n_pt = 0;
@@ -102,12 +103,20 @@ int prefetch(ba_stream *s, int k) {
   return 0;
 }
 
+// BA_STREAM_SYNC=1 (developer knob): a device synchronisation after every transfer and
+// every chunk's kernels — no overlap; separates ordering bugs from logic bugs
+bool sync_mode() {
+  static const bool on = getenv("BA_STREAM_SYNC") && getenv("BA_STREAM_SYNC")[0] == '1';
+  return on;
+}
+
 int acquire(ba_stream *s, int k) {
   if (prefetch(s, k)) return -1;
   if (s->in_pending[k]) {
     HIP_TRY(hipStreamWaitEvent(s->s_comp, s->ev_in[k], 0));
     s->in_pending[k] = 0;
   }
+  if (sync_mode()) HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
 
@@ -116,6 +125,7 @@ int release(ba_stream *s, int k, bool wrote) {
   HIP_TRY(hipEventRecord(s->ev_comp[k], s->s_comp));
   s->computed[k] = 1;
   if (wrote) s->dirty[k] = 1;
+  if (sync_mode()) HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
 
@@ -346,24 +356,41 @@ int ba_stream_finalize(ba_stream *s) {
   return 0;
 }
 
-int ba_stream_solve(ba_stream *s, const ba_options *opt, ba_iter_info *out, int cap, int *n_iter, int *converged) {
-  if (!s || !opt) return fail("ba_stream_solve: bad argument");
+int ba_stream_lm_begin(ba_stream *s, const ba_options *opt) {
+  if (!s || !opt) return fail("ba_stream_lm_begin: bad argument");
   if (!s->finalized && ba_stream_finalize(s)) return -1;
   HIP_TRY(hipSetDevice(s->device));
   int done_after = 0;
   if (stream_begin(s, opt, &done_after)) return -1;
-  int done = done_after;
-  ba_handle *h0 = s->h[0];
-  for (int it = 0; !done && it < opt->max_num_iterations; ++it) {
-    if (stream_iteration(s)) return -1;
-    if (ba::ctrl_pull(h0)) return -1;  // (synchronises the compute stream: the loop is PCIe-bound anyway)
-    done = h0->hc.done;
+  if (done_after) {
+    for (ba_handle *h : s->h) {
+      if (ba::ctrl_pull(h)) return -1;
+      h->hc.done = 1;
+      if (ba::ctrl_push(h)) return -1;
+    }
   }
-  if (ba::ctrl_pull(h0)) return -1;
+  s->lm_begun = true;
+  return 0;
+}
+
+int ba_stream_lm_iterate(ba_stream *s, int n) {
+  if (!s || !s->lm_begun) return fail("ba_stream_lm_iterate: call ba_stream_lm_begin first");
+  HIP_TRY(hipSetDevice(s->device));
+  for (int k = 0; k < n; ++k)
+    if (stream_iteration(s)) return -1;   // (iterations after convergence are device-side no-ops)
+  return 0;
+}
+
+int ba_stream_lm_sync(ba_stream *s, ba_iter_info *out, int cap, int *n_iter, int *converged) {
+  if (!s || !s->lm_begun) return fail("ba_stream_lm_sync: call ba_stream_lm_begin first");
+  HIP_TRY(hipSetDevice(s->device));
+  ba_handle *h0 = s->h[0];
+  HIP_TRY(hipStreamSynchronize(s->s_copy));
+  if (ba::ctrl_pull(h0)) return -1;  // (synchronises the compute stream)
   {
     int bp = 0;
     HIP_TRY(hipMemcpy(&bp, h0->ddev.bad_pivots, sizeof(int), hipMemcpyDeviceToHost));
-    if (bp >= ba::kFlowTimeout) return fail("ba_stream_solve: a dataflow hand-off of the reduced solve timed out");
+    if (bp >= ba::kFlowTimeout) return fail("ba_stream_lm_sync: a dataflow hand-off of the reduced solve timed out");
   }
   const int n = h0->hc.iter;
   if (n_iter) *n_iter = n;
@@ -372,7 +399,20 @@ int ba_stream_solve(ba_stream *s, const ba_options *opt, ba_iter_info *out, int 
     const int m = std::min(std::min(n, cap), h0->d.log_cap);
     HIP_TRY(hipMemcpy(out, h0->d.log, (size_t)m * sizeof(ba_iter_info), hipMemcpyDeviceToHost));
   }
-  return 0;
+  return h0->hc.done ? 1 : 0;
+}
+
+int ba_stream_solve(ba_stream *s, const ba_options *opt, ba_iter_info *out, int cap, int *n_iter, int *converged) {
+  if (ba_stream_lm_begin(s, opt)) return -1;
+  int done = opt->max_num_iterations <= 0;
+  for (int it = 0; !done && it < opt->max_num_iterations; ++it) {
+    if (ba_stream_lm_iterate(s, 1)) return -1;
+    // (one synchronisation per iteration: the loop is PCIe-bound anyway)
+    const int rc = ba_stream_lm_sync(s, nullptr, 0, nullptr, nullptr);
+    if (rc < 0) return -1;
+    done = rc;
+  }
+  return ba_stream_lm_sync(s, out, cap, n_iter, converged) < 0 ? -1 : 0;
 }
 
 int ba_stream_get_poses(ba_stream *s, double *T_jw12) {

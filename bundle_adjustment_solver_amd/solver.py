@@ -281,6 +281,15 @@ class BaProblem:
         self.M_global = int(np.sum(self.pt_fixed == 0))
         self.P = self.lib.ba_num_pairs(self.h)
 
+    def update_values(self, T_jw12=None, X3=None):
+        """New parameter values for the finalized structure (no re-planning)."""
+        T = None if T_jw12 is None else np.ascontiguousarray(T_jw12, np.float64).reshape(-1, 12)
+        X = None if X3 is None else np.ascontiguousarray(X3, np.float64).reshape(-1, 3)
+        if T is not None and T.shape[0] != self.n_pose or X is not None and X.shape[0] != self.n_pt:
+            raise ValueError("update_values: the structure is fixed (same number of poses / points)")
+        check(self.lib.ba_update_values(self.h, None if T is None else _dp(T),
+                                        None if X is None else _dp(X)), "ba_update_values")
+
     def set_allreduce(self, pyfunc):
         """pyfunc(which:int, dev_ptr:int, n_doubles:int, stream:int) -> int"""
         def _cb(user, which, ptr, n, stream):
@@ -618,6 +627,20 @@ class BaStream:
                                        C.byref(conv)), "ba_stream_solve")
         return [rows[i] for i in range(min(n.value, cap))], bool(conv.value)
 
+    def lm_begin(self, opt):
+        check(self.lib.ba_stream_lm_begin(self.h, C.byref(opt)), "ba_stream_lm_begin")
+
+    def lm_iterate(self, n):
+        check(self.lib.ba_stream_lm_iterate(self.h, n), "ba_stream_lm_iterate")
+
+    def lm_sync(self, cap=0):
+        rows = (BaIterInfo * max(cap, 1))()
+        n = C.c_int(0)
+        conv = C.c_int(0)
+        rc = check(self.lib.ba_stream_lm_sync(self.h, rows, cap, C.byref(n), C.byref(conv)),
+                   "ba_stream_lm_sync")
+        return ([rows[i] for i in range(min(n.value, cap))], n.value, bool(conv.value), bool(rc))
+
     def get_poses(self):
         out = np.zeros((self.n_pose, 12))
         check(self.lib.ba_stream_get_poses(self.h, _dp(out)), "ba_stream_get_poses")
@@ -836,6 +859,29 @@ class FullBundleAdjustmentSolver:
         self._obs_pt.append(hq.astype(np.int32))
         self._obs_uv.append(uv * SCALER)
         self.num_total_observations_ += cam.shape[0]
+
+    def ReloadParameterValues(self):
+        """(new) Read the CURRENT values of every registered pose / point object again
+        and hand them to the finalized problem (ba_update_values): a SLAM back end that
+        re-optimises the same graph with new values pays no second FinalizeParameters
+        (index assignment, plan, uploads).  The reference keeps its own copies from
+        AddPose / AddPoint across Solve calls (:44-70, :87-117) and offers no such call;
+        without it this facade, like the reference, continues from its internal state."""
+        if not self.is_parameter_finalized_:
+            return   # nothing planned yet: FinalizeParameters reads the stored copies
+        T = np.zeros((self.num_total_poses_, 12))
+        for h, (obj, row) in enumerate(self._pose_objs):
+            Tw = np.asarray(obj if row is None else obj[row], np.float64)
+            T_jw = rigid_inverse(Tw)
+            T_jw[:3, 3] *= SCALER
+            T[h] = _T44_to_12(T_jw[None])[0]
+        X = np.zeros((self.num_total_points_, 3))
+        for obj, base, cnt in self._pt_objs:
+            if cnt == 0:
+                X[base] = np.asarray(obj, np.float64).reshape(3) * SCALER
+            else:
+                X[base:base + cnt] = np.asarray(obj, np.float64) * SCALER
+        self._problem.update_values(T, X)
 
     # ---- multi-GPU plumbing (new; SURVEY.md §8e) ----
     def SetShard(self, rank, world, allreduce=None, stream=None):

@@ -76,6 +76,14 @@ class FullBundleAdjustmentSolver {
 
   bool Solve(Options options, Summary *summary = nullptr);
 
+  // (new) Read the CURRENT values behind every registered pose / point pointer again
+  // and hand them to the finalized problem (ba_update_values): re-optimising the same
+  // graph with new values costs no second FinalizeParameters.  The reference keeps its
+  // own copies from AddPose / AddPoint across Solve calls (.cpp:44-70, :87-117) and
+  // has no such call; without it this class, like the reference, continues from its
+  // internal state.
+  void ReloadParameterValues();
+
   std::string GetSolverStatistics() const;
 
   // GPU selection / console chatter (not in the reference)

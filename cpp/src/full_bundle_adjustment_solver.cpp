@@ -193,6 +193,28 @@ void FullBundleAdjustmentSolver::FinalizeParameters() {  // :182-206, :243-308, 
   is_parameter_finalized_ = true;
 }
 
+void FullBundleAdjustmentSolver::ReloadParameterValues() {
+  if (!is_parameter_finalized_) {  // nothing planned yet: refresh the copies FinalizeParameters will read
+    for (size_t p = 0; p < poses_.size(); ++p) {
+      T_jw_[p] = poses_[p]->inverse();
+      T_jw_[p].translation() = T_jw_[p].translation() * scaler_;
+    }
+    for (size_t q = 0; q < points_.size(); ++q) X_[q] = (*points_[q]) * scaler_;
+    return;
+  }
+  std::vector<double> T(12 * poses_.size()), X(3 * points_.size());
+  for (size_t p = 0; p < poses_.size(); ++p) {
+    T_jw_[p] = poses_[p]->inverse();
+    T_jw_[p].translation() = T_jw_[p].translation() * scaler_;
+    Pack12(T_jw_[p], &T[12 * p]);
+  }
+  for (size_t q = 0; q < points_.size(); ++q) {
+    X_[q] = (*points_[q]) * scaler_;
+    for (int r = 0; r < 3; ++r) X[3 * q + r] = X_[q](r);
+  }
+  Check(ba_update_values(handle_, T.data(), X.data()), "ba_update_values");
+}
+
 void FullBundleAdjustmentSolver::SetAllReduce(int (*fn)(void *, int, void *, int64_t, void *), void *user) {
   allreduce_fn_ = fn;
   allreduce_user_ = user;

@@ -98,6 +98,16 @@ int ba_set_shard(ba_handle *h, int rank, int world);
  * :243-308, :668-700: index assignment, block-sparse structure, upload. */
 int ba_finalize(ba_handle *h);
 
+/* New VALUES for the same STRUCTURE (a SLAM back end re-optimising the same graph):
+ * replaces the parameters of a finalized problem — T_jw12 for all n_pose poses
+ * and / or X3 for all n_pt points in user order, NULL = keep — without planning
+ * again (index assignment, block structure, schedules and uploads of ba_finalize
+ * stay: 0.2-0.6 s at BASELINE config C4).  Fixed flags, cameras and observations
+ * cannot change.  The next ba_solve / ba_lm_begin starts from the new values.  (The
+ * reference keeps its registered state across Solve calls, :44-70, and has no way
+ * to re-seed it short of Reset.) */
+int ba_update_values(ba_handle *h, const double *T_jw12, const double *X3);
+
 /* Host-only helper (no GPU needed): owner rank of every point under the
  * sharding rule used by ba_finalize. */
 int ba_partition_points(int n_pose, const uint8_t *pose_fixed, int n_pt,
@@ -279,6 +289,10 @@ int ba_stream_set_observations(ba_stream *s, int64_t n_obs, const int32_t *cam, 
 int ba_stream_finalize(ba_stream *s);
 int ba_stream_solve(ba_stream *s, const ba_options *opt, ba_iter_info *out, int cap,
                     int *n_iter, int *converged);
+/* the same loop in three pieces, like ba_lm_begin / ba_lm_iterate / ba_lm_sync */
+int ba_stream_lm_begin(ba_stream *s, const ba_options *opt);
+int ba_stream_lm_iterate(ba_stream *s, int n);
+int ba_stream_lm_sync(ba_stream *s, ba_iter_info *out, int cap, int *n_iter, int *converged);
 int ba_stream_get_poses(ba_stream *s, double *T_jw12);
 int ba_stream_get_points(ba_stream *s, double *X3);
 /* out6 = { device bytes of the arenas, bytes of the largest chunk, bytes of all

@@ -4,6 +4,7 @@
 // landmarks seen by many poses and a few never observed.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <set>
 #include <vector>
 
@@ -258,6 +259,27 @@ int main(int argc, char **argv) {
   for (size_t c = 0; c + 1 < pl.bchunk_lm.size(); ++c)
     CHECK(pl.bchunk_lm[c] < pl.bchunk_lm[c + 1] && pl.bchunk_lm[c + 1] - pl.bchunk_lm[c] <= ba::kSchurLandmarks,
           "backsub chunk size");
+  // ---- checksum of every array the kernels consume: the test runs this program with
+  // BA_PLAN_THREADS = 1 and = 7 and requires the same plan ----
+  {
+    auto mix = [](uint64_t h, uint64_t v) { return (h ^ v) * 0x100000001b3ull + (h >> 29); };
+    uint64_t h = 1469598103934665603ull;
+    for (auto v : pl.obs_idx) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.obs_uv) { uint64_t b; memcpy(&b, &v, 8); h = mix(h, b); }
+    for (auto v : pl.pair_pose) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.pair_lm) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.lm_obs_ptr) h = mix(h, (uint64_t)v);
+    for (auto v : pl.lm_pair_ptr) h = mix(h, (uint64_t)v);
+    for (auto v : pl.pt_user_of_int) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.pobs_idx) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.sblk_j) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.sblk_k) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.ltri) h = mix(h, (uint64_t)v);
+    for (auto v : pl.grp_pat) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.contrib_slot) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto &g : pl.lin_desc) h = mix(mix(mix(h, (uint64_t)g.p0), (uint64_t)g.o0), (uint64_t)(uint32_t)g.l0);
+    std::printf("plan checksum %016llx\n", (unsigned long long)h);
+  }
   std::printf("plan: M=%d (grouped %d in %zu+%zu pieces) P=%lld runs=%zu chunks=%zu triples=%lld (%lld in groups, +%lld big)  %s\n",
               pl.M, pl.M_grp, pl.grp32.size(), pl.grp64.size(), (long long)pl.P, pl.sup_desc.size(),
               pl.chunk_desc.size(), (long long)triples, (long long)grp_triples, (long long)big_triples,

@@ -1155,3 +1155,79 @@ def test_off_path_configs_match_oracle(name, scale, built):
         #                                          < 16 free poses and still fit a super-run)
     else:
         assert g.get_dense_info()["fill"] > 0.9
+
+
+def test_update_values_resolves_without_replanning(built):
+    """ba_update_values (new values, same structure): after a solve the problem is
+    re-seeded with its ORIGINAL values and solved again — the second trajectory and
+    result are bit-identical to the first, with no second ba_finalize; re-seeding with
+    other values follows the oracle started from those values."""
+    sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=31, pixel_sigma=0.2)
+    pr = scenes.scaled_problem(sc)
+    g = make_gpu(pr)
+    opt = dict(max_iter=10, thr_step=0, thr_cost=0)
+    rows1, _ = g.solve(make_options(**opt))
+    P1, X1 = g.get_poses(), g.get_points()[0]
+    g.update_values(pr["pose_T"], pr["pt_X"])
+    rows2, _ = g.solve(make_options(**opt))
+    assert [(r.iteration_status, r.trial_cost, r.damping_term) for r in rows1] == \
+        [(r.iteration_status, r.trial_cost, r.damping_term) for r in rows2]
+    assert np.array_equal(P1, g.get_poses()) and np.array_equal(X1, g.get_points()[0])
+    # other values (points only): the oracle built from them agrees
+    rng = np.random.default_rng(5)
+    pr2 = dict(pr)
+    pr2["pt_X"] = pr["pt_X"] + rng.uniform(-1e-3, 1e-3, pr["pt_X"].shape)
+    g.update_values(None, pr2["pt_X"])
+    pr2["pose_T"] = g.get_poses()          # (the poses stayed where the last solve left them)
+    rows3, _ = g.solve(make_options(**opt))
+    o = O.Oracle(pr2)
+    orows, _ = o.solve(O.make_options(**opt))
+    assert_same_trajectory(rows3, orows)
+    with pytest.raises(ValueError):
+        g.update_values(pr["pose_T"][:-1], None)
+
+
+def test_facade_reload_parameter_values(built):
+    """FullBundleAdjustmentSolver.ReloadParameterValues (new): the registered objects
+    are read again into the finalized problem; Solve then starts from them.  Without
+    the call a second Solve continues from the internal state, as the reference does."""
+    from bundle_adjustment_solver_amd.solver import (Camera, FullBundleAdjustmentSolver, Options,
+                                                      Summary)
+    sc = scenes.synthetic_ba_scene(20, 600, 5, True, seed=33)
+
+    def build():
+        ba = FullBundleAdjustmentSolver(0)
+        for c in range(sc["intr"].shape[0]):
+            ba.AddCamera(c, Camera(*sc["intr"][c], pose_this_to_cam0=sc["T_cj"][c]))
+        poses = sc["T_wc_init"].copy()
+        pts = sc["X_init"].copy()
+        hp = ba.AddPoseArray(poses)
+        hq = ba.AddPointArray(pts)
+        for j in np.nonzero(sc["pose_fixed"])[0]:
+            ba.MakePoseFixed(int(hp[j]))
+        for c in range(sc["intr"].shape[0]):
+            m = sc["obs_cam"] == c
+            ba.AddObservations(c, hp[sc["obs_pose"][m]], hq[sc["obs_pt"][m]], sc["obs_uv"][m])
+        return ba, poses, pts
+
+    opt = Options()
+    opt.iteration_handle.max_num_iterations = 8
+    opt.convergence_handle.threshold_cost_change = 0.0
+    opt.convergence_handle.threshold_step_size = 0.0
+    ba, poses, pts = build()
+    s1 = Summary()
+    ba.Solve(opt, s1)
+    first = [(i.iteration_status, i.cost) for i in s1.optimization_info_list_]
+    solved_pts = pts.copy()
+    # put the initial values back into the caller's arrays and reload them
+    poses[...] = sc["T_wc_init"]
+    pts[...] = sc["X_init"]
+    ba.ReloadParameterValues()
+    s2 = Summary()
+    ba.Solve(opt, s2)
+    assert [(i.iteration_status, i.cost) for i in s2.optimization_info_list_] == first
+    assert np.array_equal(pts, solved_pts)
+    # without a reload the next Solve continues: its first cost is the last one's
+    s3 = Summary()
+    ba.Solve(opt, s3)
+    assert s3.optimization_info_list_[0].cost < first[0][1] * 0.5

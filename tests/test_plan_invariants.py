@@ -20,7 +20,7 @@ def plan_check(tmp_path_factory):
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", CSRC,
                     os.path.join(ROOT, "tests", "cpp", "plan_check.cpp"),
                     os.path.join(CSRC, "ba_plan.cpp"),
-                    os.path.join(CSRC, "ba_dense_sched.cpp"), "-o", exe], check=True)
+                    os.path.join(CSRC, "ba_dense_sched.cpp"), "-o", exe, "-pthread"], check=True)
     return exe
 
 
@@ -44,6 +44,22 @@ def test_plan_invariants(plan_check, args, env):
     r = subprocess.run([plan_check] + args, env=dict(os.environ, **env),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
+
+
+@pytest.mark.parametrize("args", [["120", "30000", "5", "2"], ["90", "2000", "37", "2"],
+                                  ["300", "100000", "5", "2"]])
+def test_threaded_plan_equals_the_serial_plan(plan_check, args):
+    """The planner's per-landmark passes run on host threads (csrc/ba_plan.cpp
+    parallel_for; replaces reference :182-206, :243-308, :668-700).  Every array the
+    kernels consume must be identical for 1 and 7 threads (checksum printed by
+    tests/cpp/plan_check.cpp), and the invariants hold for both."""
+    sums = []
+    for nt in ("1", "7"):
+        r = subprocess.run([plan_check] + args, env=dict(os.environ, BA_PLAN_THREADS=nt),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
+        sums.append([l for l in r.stdout.splitlines() if l.startswith("plan checksum")])
+    assert sums[0] and sums[0] == sums[1], sums
 
 
 def test_dense_level_schedule_executes_to_the_dense_solution(tmp_path):
