@@ -14,6 +14,7 @@
 // component are set to zero.
 #include "ba_device.h"
 #include "ba_dense_sched.h"
+#include "ba_tile16.h"
 
 #include <cstdlib>
 #include <vector>
@@ -43,149 +44,8 @@ __global__ __launch_bounds__(256) void k_dense_init(double *L, int ld,
   }
 }
 
-// ---- step 1: Cholesky of the 64x64 diagonal block (one workgroup) ---------
-// Left-looking over four 16-column panels held in LDS.  The bulk (panel
-// update, TRSM of the rows below) runs on the fp64 matrix cores; the only
-// serial part is the register-resident 16x16 tile factorisation below, which
-// produces L_T and E_T = L_T^-T in the same 16 steps (the column operations
-// that turn A into L turn I into L^-T).
-//
-// Outputs per block (workspace `ws`, kDenseWsPerBlock doubles):
-//   ws[0 .. 4095]      L11, column-major 64x64, zero above the diagonal
-//   ws[4096 + 256 p..] E_pp = L_pp^-T (16x16, row-major, upper incl. diag)
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-  union { double d; int i[2]; } u;
-  u.d = v;
-  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
-  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
-  return u.d;
-}
-
-// Lane (r = lane&15, q = lane>>4) holds g[j] = G[r][4j+q].  On entry the lower
-// triangle (r >= c) is the SPD tile and the strict upper part is 0; on exit the
-// lower triangle is L_T and the strict upper part is L_T^-T; `dinv` receives
-// the diagonal of L_T^-T (= 1/L_cc) in the lane that holds G[c][c].  A
-// non-positive pivot zeroes its column.  Returns the number of such pivots
-// (wave-uniform).
-//
-// Blocked by 4, with UNSCALED columns (LDL^T style) inside the sweep.  The column
-// operations that turn A into L turn I into L^-T (the strict upper part of the
-// tile is the folded image of I), so for every 4-column block
-//  (1) every lane fetches the 4x4 diagonal block (v_readlane: uniform) and
-//      eliminates it redundantly: the dependent chain per pivot is one
-//      v_rcp_f64 + 2 Newton steps + two FMAs, with no cross-lane traffic on it;
-//  (2) every row applies the block's unit-lower factor to its four block entries
-//      (three cross-lane reads, issued before the chain starts);
-//  (3) the rank-4 update of ALL trailing columns (rows of L and rows of the
-//      folded inverse alike) is ONE v_mfma_f64_16x16x4_f64 (operands y r_k and
-//      y), whose accumulator layout (row = lane&15, column = 4*reg + lane>>4) is
-//      exactly this register layout.
-// The 1/sqrt(d_c) scaling of all 16 columns happens once afterwards, four
-// independent chains per lane.  16 dependent column steps of ~460 cycles became
-// 4 block steps.
-__device__ __forceinline__ double rcp_refined(double d, bool ok) {
-  const double ds = ok ? d : 1.0;
-  double ri = __builtin_amdgcn_rcp(ds);
-  ri = fma(fma(-ds, ri, 1.0), ri, ri);
-  ri = fma(fma(-ds, ri, 1.0), ri, ri);
-  return ok ? ri : 0.0;
-}
-__device__ __forceinline__ double sel4(int k, double a0, double a1, double a2, double a3) {
-  return k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;
-}
-__device__ __forceinline__ int tile16_potrf_inv(double g[4], int lane, double &dinv) {
-  const int r = lane & 15, q = lane >> 4;
-  int nbad = 0;
-#pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    const int c0 = 4 * kb;
-    // this row's entries of the block columns (own value for k == q)
-    const double a0 = __shfl(g[kb], r, 64), a1 = __shfl(g[kb], r + 16, 64),
-                 a2 = __shfl(g[kb], r + 32, 64), a3 = __shfl(g[kb], r + 48, 64);
-    // diagonal block, lower part: D[i][k] lives in lane (c0 + i, k)
-    const double d00 = readlane_f64(g[kb], c0 + 0);
-    const double w10 = readlane_f64(g[kb], c0 + 1), d11 = readlane_f64(g[kb], c0 + 1 + 16);
-    const double w20 = readlane_f64(g[kb], c0 + 2), d21 = readlane_f64(g[kb], c0 + 2 + 16),
-                 d22 = readlane_f64(g[kb], c0 + 2 + 32);
-    const double w30 = readlane_f64(g[kb], c0 + 3), d31 = readlane_f64(g[kb], c0 + 3 + 16),
-                 d32 = readlane_f64(g[kb], c0 + 3 + 32), d33 = readlane_f64(g[kb], c0 + 3 + 48);
-    // unit-lower LDL^T of the 4x4 block: w = unscaled column entries, l = w / pivot
-    const bool ok0 = d00 > 1e-300;
-    const double r0 = rcp_refined(d00, ok0);
-    const double l10 = w10 * r0, l20 = w20 * r0, l30 = w30 * r0;
-    const double p1 = fma(-l10, w10, d11);
-    const double w21 = fma(-l20, w10, d21), w31 = fma(-l30, w10, d31);
-    const bool ok1 = p1 > 1e-300;
-    const double r1 = rcp_refined(p1, ok1);
-    const double l21 = w21 * r1, l31 = w31 * r1;
-    const double p2 = fma(-l21, w21, fma(-l20, w20, d22));
-    const double w32 = fma(-l31, w21, fma(-l30, w20, d32));
-    const bool ok2 = p2 > 1e-300;
-    const double r2 = rcp_refined(p2, ok2);
-    const double l32 = w32 * r2;
-    const double p3 = fma(-l32, w32, fma(-l31, w31, fma(-l30, w30, d33)));
-    const bool ok3 = p3 > 1e-300;
-    const double r3 = rcp_refined(p3, ok3);
-    nbad += (ok0 ? 0 : 1) + (ok1 ? 0 : 1) + (ok2 ? 0 : 1) + (ok3 ? 0 : 1);
-    // y = a Ltilde^-T: the unscaled column entries of this row (rows below the
-    // block: L times sqrt(d); rows above it: the folded inverse, same transform;
-    // block rows: at and below the diagonal y reproduces their w / pivots)
-    const double y0 = a0;
-    const double y1 = fma(-y0, l10, a1);
-    const double y2 = fma(-y1, l21, fma(-y0, l20, a2));
-    const double y3 = fma(-y2, l32, fma(-y1, l31, fma(-y0, l30, a3)));
-    // above the diagonal a block row holds its folded identity row
-    // e_rb Ltilde^-T (unit upper triangular)
-    const int rb = r - c0;  // 0..3 inside the block
-    const bool inb = rb >= 0 && rb < 4;
-    const double e0 = rb == 0 ? 1.0 : 0.0, e1 = rb == 1 ? 1.0 : 0.0, e2 = rb == 2 ? 1.0 : 0.0;
-    const double u1 = fma(-e0, l10, e1);
-    const double u2 = fma(-u1, l21, fma(-e0, l20, e2));
-    const double u3 = fma(-u2, l32, fma(-u1, l31, fma(-e0, l30, rb == 3 ? 1.0 : 0.0)));
-    const double ya = sel4(q, y0, y1, y2, y3);
-    const double yu = sel4(q, e0, u1, u2, u3);
-    const double rq = sel4(q, r0, r1, r2, r3);
-    g[kb] = (inb && q > rb) ? yu : ya;
-    // rank-4 update of the trailing columns c2 > c0 + 3:
-    //   G[row][c2] -= sum_k B[row][k] * (y[c2][k] r_k)
-    // A operand: the panel below the block, scaled by the pivots' reciprocals;
-    // B operand: the panel as every ROW sees it (rows below: y; folded inverse
-    // rows above: y; block rows: their folded identity row, zero left of its 1)
-    if (kb < 3) {
-      const double aop = r > c0 + 3 ? -ya * rq : 0.0;
-      const double bop = inb ? (q >= rb ? yu : 0.0) : ya;
-      v4f64 acc = (v4f64){g[0], g[1], g[2], g[3]};
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-#pragma unroll
-      for (int j = kb + 1; j < 4; ++j) {
-        // entries right of the diagonal in rows below the block belong to folded
-        // identity rows that are not active yet: they stay zero
-        const int c = 4 * j + q;
-        g[j] = (r > c0 + 3 && c > r) ? 0.0 : acc[j];
-      }
-    }
-  }
-  // scale column c by 1/sqrt(d_c) (v_rsq_f64 + Newton), diagonal = sqrt(d_c);
-  // the folded inverse gets the same column scaling, its diagonal is 1/sqrt(d_c)
-  dinv = 0.0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = 4 * j + q;
-    const double d = __shfl(g[j], c + 16 * q, 64);  // pivot of this lane's column
-    const bool ok = d > 1e-300;
-    const double ds = ok ? d : 1.0;
-    double y = __builtin_amdgcn_rsq(ds);
-    const double hd = 0.5 * ds;
-#pragma unroll
-    for (int nr = 0; nr < 3; ++nr) y = y * fma(-hd * y, y, 1.5);
-    double sq = ds * y;
-    sq = fma(fma(-sq, sq, ds), 0.5 * y, sq);
-    y = fma(fma(-sq, y, 1.0), y, y);
-    g[j] = ok ? ((r == c) ? sq : g[j] * y) : 0.0;
-    if (r == c) dinv = ok ? y : 0.0;
-  }
-  return nbad;
-}
+using tile16::readlane_f64;
+using tile16::tile16_potrf_inv2;
 // dropped pivots are counted per handle (ba_get_dropped_pivots); the integer
 // atomic runs only when a factorisation actually meets one
 __device__ __forceinline__ void count_bad_pivots(int *bad, int n, int lane) {
@@ -305,7 +165,7 @@ __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int 
         g[j] = (r >= c) ? Lb[(16 * p + c) * LS + 16 * p + r] : 0.0;
       }
       double dinv;
-      count_bad_pivots(bad, tile16_potrf_inv(g, lane, dinv), lane);
+      count_bad_pivots(bad, tile16_potrf_inv2(g, lane, dinv), lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = 4 * j + q;

@@ -741,20 +741,26 @@ def test_config_c3_c4_trajectories_match_fast_oracle(name, iters, built):
     assert rows[-1].cost < 0.02 * rows[0].cost     # well past the first steps
 
 
-@pytest.mark.parametrize("name", ["C3", "C4"])
-def test_config_c3_c4_to_the_solvers_own_stop_match_fast_oracle(name, built):
+@pytest.mark.parametrize("name,thr_cost", [("C3", 1e-6), ("C4", 1e-7)])
+def test_config_c3_c4_to_the_solvers_own_stop_match_fast_oracle(name, thr_cost, built):
     """BASELINE configs C3 and C4 (the headline) run with the options SURVEY.md
     §8(d) names for them — lambda0 100, ratios 0.33f / 3.0f, Huber 1.0, thresholds
     1e-6f, at most 50 iterations — until the solver's OWN stopping rule ends the
     loop (reference :971-979: average step or cost change below the threshold, or
     the iteration cap), GPU and fast-solve oracle alike: same number of iterations,
     same convergence flag, identical status / lambda sequences, trial costs to 1e-7,
-    and the three north-star metrics per pose / per point <= 1e-4 at the end."""
+    and the three north-star metrics per pose / per point <= 1e-4 at the end.
+    (C4 with threshold_cost_change 1e-7: at 1e-6 the stop is not determined by the
+    arithmetic — the cost changes of the C4 trajectory bottom out at 2e-6 around
+    iteration 38, i.e. within 2x of the threshold and at a relative 5e-10 of the cost,
+    far below the 1e-7 to which any two summation orders of the reduced solve agree;
+    the GPU stopped at iteration 40 or ran to the cap of 50 depending on the rounding
+    of the 16x16 tile factorisation, the oracle ran to 50.)"""
     sc = scenes.config_scene(name)
     pr = scenes.scaled_problem(sc)
     g, o = make_gpu(pr), O.Oracle(pr)
     o.set_fast_solve(True)
-    kw = dict(max_iter=50, thr_step=1e-6, thr_cost=1e-6)
+    kw = dict(max_iter=50, thr_step=1e-6, thr_cost=thr_cost)
     rows, conv = g.solve(make_options(**kw))
     orows, oconv = o.solve(O.make_options(**kw))
     assert len(rows) == len(orows) and conv == oconv, (len(rows), len(orows), conv, oconv)
