@@ -41,6 +41,8 @@ WORKLOADS = {
     "C4": "C4 stereo 6-DoF: 1000 poses / 500k landmarks / 5M obs",
     # off the headline's happy path (not BASELINE configs; measured because the
     # headline scene avoids these code paths)
+    "C4R": "off-path C4R stereo: C4 with 15 % of the observations dropped at random "
+           "(1000 poses / 500k landmarks / ~4.3M obs): irregular observation patterns",
     "W20": "off-path W20 mono: 500 poses / 100k landmarks / 2M obs, 20-pose windows "
            "(k_schur_partial: global triple list)",
     "DENSE1K": "off-path DENSE1K mono: 1000 poses / 60k landmarks / 480k obs, 8 random "

@@ -153,6 +153,7 @@ SIGNATURES = {
     "ba_get_dense_info": (C.c_int, [_P, _D]),
     "ba_get_schur_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ba_get_lin_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "ba_get_mask_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ba_get_dropped_pivots": (C.c_int, [_P, C.POINTER(C.c_int64), C.c_int]),
     "ba_dense_spd_solve": (C.c_int, [_P, C.c_int, _D, _D, _D, _D]),
     "ba_pose_only_mono6": (C.c_int, [_P, _F, _F, C.c_int, C.c_float, C.c_float,

@@ -501,6 +501,7 @@ int ba_finalize(ba_handle *h) {
     // k_lin_grp: observation patterns, pose-side partial sums of the group pieces
     d.lin_chunk0 = pl.lin_groups ? pl.n_bchunk_grp : 0;
     d.n_lin_desc = (int)pl.lin_desc.size();
+    d.n_lin_plain = pl.n_lin_plain;
     d.n_bs_grp = d.n_lin_desc;
     d.n_lm_part = d.n_bs_grp + (d.n_bchunk - d.lin_chunk0 + ba::kBsChunks - 1) / ba::kBsChunks;
     d.n_lin_cost = d.n_bchunk + d.n_lin_desc;
@@ -1010,7 +1011,9 @@ int ba_get_stage_ms(ba_handle *h, double out8[8], int reset) {
 // readers
 int ba_num_opt_poses(ba_handle *h) { return (h && h->finalized) ? h->plan.N : -1; }
 int ba_num_opt_points(ba_handle *h) { return (h && h->finalized) ? h->plan.M : -1; }
-int64_t ba_num_pairs(ba_handle *h) { return (h && h->finalized) ? h->plan.P : -1; }
+// (pairs that a masked covisibility group pads in — no observation, W = 0 — are an
+//  internal device of the layout: the readers do not show them)
+int64_t ba_num_pairs(ba_handle *h) { return (h && h->finalized) ? h->plan.P - h->plan.n_pair_pad : -1; }
 int64_t ba_num_schur_blocks(ba_handle *h) { return (h && h->finalized) ? h->plan.B : -1; }
 int64_t ba_num_schur_triples(ba_handle *h) { return (h && h->finalized) ? h->plan.T : -1; }
 
@@ -1154,9 +1157,15 @@ int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18) {
   if (!h || !h->finalized) return fail("ba_get_pairs: not finalized");
   if (use_device(h)) return -1;
   const ba::Plan &pl = h->plan;
-  for (int64_t p = 0; p < pl.P; ++p) {
-    if (pair_i) pair_i[p] = pl.iopt_of_user[pl.pt_user_of_int[pl.pair_lm[p]]];
-    if (pair_j) pair_j[p] = pl.pair_pose[p];
+  auto padded = [&](int64_t p) { return !pl.pair_pad.empty() && pl.pair_pad[p]; };
+  {
+    int64_t o = 0;
+    for (int64_t p = 0; p < pl.P; ++p) {
+      if (padded(p)) continue;
+      if (pair_i) pair_i[o] = pl.iopt_of_user[pl.pt_user_of_int[pl.pair_lm[p]]];
+      if (pair_j) pair_j[o] = pl.pair_pose[p];
+      ++o;
+    }
   }
   if (W18) {
     if (pull_ctrl(h)) return -1;  // synchronises the stream
@@ -1164,15 +1173,18 @@ int ba_get_pairs(ba_handle *h, int32_t *pair_i, int32_t *pair_j, double *W18) {
     std::vector<double> w12((size_t)pl.P * ba::kWStride);
     if (pl.P > 0)
       HIP_TRY(hipMemcpy(w12.data(), h->d.W[h->hc.lcur], w12.size() * sizeof(double), hipMemcpyDeviceToHost));
+    int64_t o = 0;
     for (int64_t p = 0; p < pl.P; ++p) {
+      if (padded(p)) continue;
       const double *k = &w12[(size_t)p * ba::kWStride];
-      double *W = W18 + (size_t)p * 18;
+      double *W = W18 + (size_t)o * 18;
       for (int e = 0; e < 9; ++e) W[e] = k[e];
       for (int c = 0; c < 3; ++c) {
         W[9 + c] = k[10] * k[6 + c] - k[11] * k[3 + c];
         W[12 + c] = k[11] * k[c] - k[9] * k[6 + c];
         W[15 + c] = k[9] * k[3 + c] - k[10] * k[c];
       }
+      ++o;
     }
   }
   return 0;
@@ -1286,6 +1298,23 @@ int ba_get_lin_info(ba_handle *h, int64_t out4[4]) {
   out4[1] = obs;
   out4[2] = (int64_t)pl.bchunk_lm.size() - 1 - (pl.lin_groups ? pl.n_bchunk_grp : 0);
   out4[3] = pl.n_pobs;
+  return 0;
+}
+
+int ba_get_mask_info(ba_handle *h, int64_t out4[4]) {
+  if (!h || !h->finalized || !out4) return fail("ba_get_mask_info: bad argument");
+  const ba::Plan &pl = h->plan;
+  int64_t lm = 0;
+  for (const auto &g : pl.grp_range) lm += g.masked ? g.nl : 0;
+  out4[0] = (int64_t)pl.lin_desc.size() - pl.n_lin_plain;
+  out4[1] = lm;
+  out4[2] = pl.n_obs - (pl.n_obs_global > 0 && h->world == 1 ? pl.n_obs_global : pl.n_obs);
+  {  // (sharded: count the padded slots themselves)
+    int64_t pad = 0;
+    for (int64_t s2 = 0; s2 < pl.n_obs; ++s2) pad += !(pl.obs_uv[2 * s2] == pl.obs_uv[2 * s2]);
+    out4[2] = pad;
+  }
+  out4[3] = pl.n_pair_pad;
   return 0;
 }
 

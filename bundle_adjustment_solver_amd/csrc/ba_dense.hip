@@ -45,7 +45,19 @@ __global__ __launch_bounds__(256) void k_dense_init(double *L, int ld,
 }
 
 using tile16::readlane_f64;
-using tile16::tile16_potrf_inv2;
+// -DBA_TILE16_OLD: the first form of the tile factorisation (developer comparison)
+#ifdef BA_TILE16_OLD
+#define BA_TILE16_POTRF tile16::tile16_potrf_inv
+#elif defined(BA_TILE16_CALL)
+// ONE copy of the routine per kernel instead of one per (unrolled) panel: the second
+// panel of a tile finds its ~8 KB of straight-line code in the instruction cache
+__device__ __attribute__((noinline)) int tile16_potrf_call(double g[4], int lane, double &dinv) {
+  return tile16::tile16_potrf_inv2(g, lane, dinv);
+}
+#define BA_TILE16_POTRF tile16_potrf_call
+#else
+#define BA_TILE16_POTRF tile16::tile16_potrf_inv2
+#endif
 // dropped pivots are counted per handle (ba_get_dropped_pivots); the integer
 // atomic runs only when a factorisation actually meets one
 __device__ __forceinline__ void count_bad_pivots(int *bad, int n, int lane) {
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(256) void k_chol_tail(const double *L, int ld, int 
         g[j] = (r >= c) ? Lb[(16 * p + c) * LS + 16 * p + r] : 0.0;
       }
       double dinv;
-      count_bad_pivots(bad, tile16_potrf_inv2(g, lane, dinv), lane);
+      count_bad_pivots(bad, BA_TILE16_POTRF(g, lane, dinv), lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = 4 * j + q;

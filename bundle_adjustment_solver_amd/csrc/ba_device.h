@@ -108,6 +108,7 @@ struct DevProblem {
   };
   LinDesc *lin_desc;
   int n_lin_desc;
+  int n_lin_plain;  // pieces [0, n_lin_plain): exact groups; behind them: masked (superset) groups
   GrpDesc *grp32, *grp64;  // pose sets of <= 5 / 6..10 poses
   int n_grp32, n_grp64;
   // k_lin_grp (groups linearised landmark and pose side in one pass): per pattern

@@ -415,7 +415,8 @@ struct ObsRec<false> {
     const double *cam_ = LDSCAM ? (const double *)(cams_s + ccam * 16)          \
                                 : (const double *)(d.cams + (size_t)ccam * 16); \
     project(cam_, TC, XC[0], XC[1], XC[2], cuv.x, cuv.y, g_);                   \
-    acc += sqrt(g_.r0 * g_.r0 + g_.r1 * g_.r1);                                 \
+    /* (a padded slot of a masked covisibility group has uv = NaN: no observation) */ \
+    acc += cuv.x == cuv.x ? sqrt(g_.r0 * g_.r0 + g_.r1 * g_.r1) : 0.0;          \
     ccam = ncam_;                                                               \
     cuv = nuv_;                                                                 \
   }
@@ -696,8 +697,14 @@ __device__ long long g_lg_dbg[64];
 #else
 #define LG_STAMP()
 #endif
-template <bool LDSCAM>
-__global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
+// MASKED: pieces of superset groups (ba_plan.h GrpRange::masked).  A slot whose uv is
+// NaN is a padded one — the landmark has no observation there: weight 0, residual 0,
+// no cost — and the pair's last WRITER (reference :826) is the last VALID slot of its
+// pose in this landmark, found from a ballot of the step's valid lanes; when a pose has
+// no valid slot at all its static last slot stores the (zero-K) record, so that the W
+// image never keeps a previous step's entry.
+template <bool LDSCAM, bool MASKED>
+__global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, int piece0) {
 #ifdef BA_LG_DBG
   __shared__ long long lg_s[64];
   const bool lg_on = blockIdx.x == 300 && threadIdx.x == 0;
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
   __shared__ double cams_s[kCamLds * 16];
   __shared__ double smc[4];
   __shared__ int slot_b[10], slot_e[10];  // pattern slots of pose jj of the group (<= kGrpMaxPoses poses)
-  const int bid = blockIdx.x;
+  const int bid = piece0 + blockIdx.x;
   const DevProblem::LinDesc *gp = d.lin_desc + bid;
   const int64_t p0 = gp->p0, o0 = gp->o0;
   const int l0 = gp->l0, nl = gp->nl, dd = gp->d, no = gp->no, pat0 = gp->pat0;
@@ -748,6 +755,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
   }
   __syncthreads();  // cams_s, slot_b
   load_cam<LDSCAM>(d, cams_s, cam_id, cam);
+  // MASKED: this lane's slot range of its pose inside the landmark's pattern word
+  // (two lane constants: the bits of the LATER slots of this lane's pose and the bits of
+  //  all slots of the pose, positions inside the landmark's no-bit word)
+  unsigned later_bits = 0u, pose_bits = 0u;
+  if (MASKED && opt) {
+    const int sb_l = slot_b[jj], se_l = slot_e[jj];
+    const unsigned upto_e = se_l >= 32 ? 0xffffffffu : ((1u << se_l) - 1u);
+    pose_bits = upto_e & ~((1u << sb_l) - 1u);
+    later_bits = oo + 1 >= 32 ? 0u : (upto_e & ~((1u << (oo + 1)) - 1u));
+  }
   double *__restrict__ Wg = d.W[lb];
   double *__restrict__ Cg = d.Cu[lb];
   double *__restrict__ bg = d.b[lb];
@@ -837,9 +854,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
     }                                                                               \
     const int il0_ = (st * 4 + wv) * nlw;                                           \
     const int il_ = il0_ + ilw;                                                     \
-    const bool valid_ = lane_on && il_ < nl;                                        \
+    const bool valid_ = lane_on && il_ < nl && (!MASKED || uvq[CUR].x == uvq[CUR].x); \
+    bool wr_ = lastw;                                                               \
+    if (MASKED) {                                                                   \
+      const unsigned long long vb_ = __ballot(valid_);                              \
+      const unsigned mine_ = (unsigned)(vb_ >> (lane - oo));                        \
+      wr_ = opt && (valid_ ? (mine_ & later_bits) == 0u : (lastw && (mine_ & pose_bits) == 0u)); \
+    }                                                                               \
     ObsGeom g;                                                                      \
     project(cam, T, Xq[CUR][0], Xq[CUR][1], Xq[CUR][2], uvq[CUR].x, uvq[CUR].y, g); \
+    if (MASKED) {                                                                   \
+      g.r0 = valid_ ? g.r0 : 0.0;                                                   \
+      g.r1 = valid_ ? g.r1 : 0.0;                                                   \
+    }                                                                               \
     cost_acc += valid_ ? sqrt(g.r0 * g.r0 + g.r1 * g.r1) : 0.0;                     \
     double w, G[6], Rm[6], Q[12], cbv[9], kk[12];                                   \
     weight_and_G(cam, g, huber, w, G);                                              \
@@ -889,7 +916,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel) {
     {                                                                               \
       double *cb = cbw + lane * 9;                                                  \
       _Pragma("unroll") for (int e_ = 0; e_ < 9; ++e_) cb[e_] = cbv[e_];            \
-      if (lastw && lane_on) {                                                       \
+      if (wr_ && lane_on) {                                                         \
         _Pragma("unroll") for (int r = 0; r < 6; ++r)                               \
           stgW_mine[r] = make_double2(kk[2 * r], kk[2 * r + 1]);                    \
       }                                                                             \
@@ -2601,10 +2628,14 @@ void launch_cost(const DevProblem &d, int sel, int64_t begin, hipStream_t s) {
 
 void launch_lin_landmarks(const DevProblem &d, int sel, hipStream_t s) {
   if (d.lin_chunk0 > 0) {  // covisibility groups: landmark and pose side in one pass
-    if (d.n_cam <= kCamLds)
-      BA_LAUNCH(K_LIN_GRP, k_lin_grp<true>, dim3(d.n_lin_desc), dim3(kBlock), s, d, sel);
-    else
-      BA_LAUNCH(K_LIN_GRP, k_lin_grp<false>, dim3(d.n_lin_desc), dim3(kBlock), s, d, sel);
+    const int n_plain = d.n_lin_plain, n_mask = d.n_lin_desc - d.n_lin_plain;
+    if (d.n_cam <= kCamLds) {
+      if (n_plain > 0) BA_LAUNCH(K_LIN_GRP, (k_lin_grp<true, false>), dim3(n_plain), dim3(kBlock), s, d, sel, 0);
+      if (n_mask > 0) BA_LAUNCH(K_LIN_GRP, (k_lin_grp<true, true>), dim3(n_mask), dim3(kBlock), s, d, sel, n_plain);
+    } else {
+      if (n_plain > 0) BA_LAUNCH(K_LIN_GRP, (k_lin_grp<false, false>), dim3(n_plain), dim3(kBlock), s, d, sel, 0);
+      if (n_mask > 0) BA_LAUNCH(K_LIN_GRP, (k_lin_grp<false, true>), dim3(n_mask), dim3(kBlock), s, d, sel, n_plain);
+    }
   }
   const int nch = d.n_bchunk - d.lin_chunk0;
   if (nch <= 0) return;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -385,30 +386,162 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         });
       }
     }
-    std::vector<uint8_t> grouped(M0, 0);
+    // ---- groups.  A run of candidates with the IDENTICAL pattern is an exact group (as
+    // before).  SUPERSET groups (round 3) take what real visibility leaves of that —
+    // occlusion, image borders, track loss make the patterns of one pose window differ
+    // from landmark to landmark: all candidates with the same pose SPAN (first and last
+    // observing pose) form one group whose pattern is the UNION of theirs; a member's
+    // missing observations become padded slots (uv = NaN: weight 0, no cost) and its
+    // missing pairs zero W records, so that the group kernels keep their one-lane-per-
+    // (landmark, slot) layout.  Landmarks that lost their first or last pose altogether
+    // join a group whose union contains their pattern.  (BA_NO_SUPERSET=1: exact groups
+    // only; masks need k_lin_grp, so also off with BA_NO_LINGRP=1.)
+    struct GroupBuild {
+      std::vector<uint64_t> upat;     // union pattern, sorted
+      std::vector<int32_t> members;   // preliminary landmark indices
+      int d = 0;
+      bool masked = false;
+      int32_t last_pose = 0;
+    };
+    std::vector<GroupBuild> groups;
+    std::vector<int32_t> group_of(M0, -1);
+    static const bool no_superset_env = getenv("BA_NO_SUPERSET") && getenv("BA_NO_SUPERSET")[0] == '1';
+    const bool superset = pl.lin_groups && !no_superset_env;
+    auto first_pose = [&](int i) { return (int32_t)(pat[kp[i]] >> 32); };
+    auto last_pose = [&](int i) { return (int32_t)(pat[kp[i + 1] - 1] >> 32); };
+    // a member of a superset group must list its (pose, camera) entries in strictly
+    // increasing order: the slots of the union are in that order, and the pair's last
+    // WRITER (reference :826: the last inserted observation of a pose) is then the last
+    // valid slot of the pose.  (Duplicates and cameras inserted in descending order:
+    // exact groups only.)
+    auto has_dup = [&](int i) {
+      for (int64_t t = kp[i] + 1; t < kp[i + 1]; ++t)
+        if (pat[t] <= pat[t - 1]) return true;
+      return false;
+    };
+    auto dopt_of = [&](const std::vector<uint64_t> &u) {
+      int n = 0;
+      int64_t last = -1;
+      for (uint64_t w : u) {
+        const int64_t ji = (int64_t)(w >> 32);
+        if (ji < N && ji != last) ++n;
+        last = ji;
+      }
+      return n;
+    };
+    auto exact_runs = [&](size_t lo, size_t hi) {
+      size_t a = lo;
+      while (a < hi) {
+        size_t b = a + 1;
+        while (b < hi && same_sig(cand[a], cand[b])) ++b;
+        if ((int)(b - a) >= kGrpMinLandmarks) {
+          GroupBuild gb;
+          gb.upat.assign(pat.begin() + kp[cand[a]], pat.begin() + kp[cand[a] + 1]);
+          gb.d = dop[cand[a]];
+          gb.last_pose = last_pose(cand[a]);
+          for (size_t t = a; t < b; ++t) {
+            gb.members.push_back(cand[t]);
+            group_of[cand[t]] = (int32_t)groups.size();
+          }
+          groups.push_back(std::move(gb));
+        }
+        a = b;
+      }
+    };
+    if (!superset) {
+      exact_runs(0, cand.size());
+    } else {
+      // buckets of equal (first pose, last pose); inside a bucket the pattern order stays
+      std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) {
+        const int32_t fx = first_pose(x), fy = first_pose(y);
+        if (fx != fy) return fx < fy;
+        return last_pose(x) < last_pose(y);
+      });
+      size_t a = 0;
+      std::vector<uint64_t> uni;
+      while (a < cand.size()) {
+        size_t b = a + 1;
+        while (b < cand.size() && first_pose(cand[b]) == first_pose(cand[a]) && last_pose(cand[b]) == last_pose(cand[a]))
+          ++b;
+        if (same_sig(cand[a], cand[b - 1])) {  // (sorted by pattern: first == last => all equal)
+          exact_runs(a, b);
+          a = b;
+          continue;
+        }
+        // union of the duplicate-free members' patterns
+        uni.clear();
+        int64_t slots = 0;
+        int n_el = 0;
+        for (size_t t = a; t < b; ++t) {
+          const int i = cand[t];
+          if (has_dup(i)) continue;
+          uni.insert(uni.end(), pat.begin() + kp[i], pat.begin() + kp[i + 1]);
+          slots += deg(i);
+          ++n_el;
+        }
+        std::sort(uni.begin(), uni.end());
+        uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+        const int du = dopt_of(uni);
+        if (n_el >= kGrpMinLandmarks && (int)uni.size() <= kGrpMaxObs && du <= kGrpMaxPoses &&
+            (double)slots >= 0.55 * (double)n_el * (double)uni.size()) {
+          GroupBuild gb;
+          gb.upat = uni;
+          gb.d = du;
+          gb.last_pose = (int32_t)(uni.back() >> 32);
+          for (size_t t = a; t < b; ++t) {
+            const int i = cand[t];
+            if (has_dup(i)) continue;
+            gb.members.push_back(i);
+            group_of[i] = (int32_t)groups.size();
+            if (deg(i) < (int)uni.size()) gb.masked = true;
+          }
+          groups.push_back(std::move(gb));
+          // (members with duplicate observations: exact runs among themselves)
+        } else {
+          exact_runs(a, b);
+        }
+        a = b;
+      }
+      // leftovers join a group whose union contains their pattern
+      std::vector<std::vector<int32_t>> by_first(in.n_pose + 1);
+      for (size_t gidx = 0; gidx < groups.size(); ++gidx)
+        by_first[(size_t)(groups[gidx].upat.front() >> 32)].push_back((int32_t)gidx);
+      for (int i : cand) {
+        if (group_of[i] >= 0 || has_dup(i)) continue;
+        const int32_t f = first_pose(i), l = last_pose(i);
+        bool joined = false;
+        for (int32_t g0 = f; g0 >= 0 && g0 > f - kGrpMaxObs && !joined; --g0)
+          for (int32_t gidx : by_first[g0]) {
+            GroupBuild &gb = groups[gidx];
+            if (gb.last_pose < l) continue;
+            if (!std::includes(gb.upat.begin(), gb.upat.end(), pat.begin() + kp[i], pat.begin() + kp[i + 1])) continue;
+            gb.members.push_back(i);
+            group_of[i] = gidx;
+            if (deg(i) < (int)gb.upat.size()) gb.masked = true;
+            joined = true;
+            break;
+          }
+      }
+    }
     std::vector<int32_t> neworder;
     neworder.reserve(M0);
-    size_t a = 0;
-    while (a < cand.size()) {
-      size_t b = a + 1;
-      while (b < cand.size() && same_sig(cand[a], cand[b])) ++b;
-      if ((int)(b - a) >= kGrpMinLandmarks) {
-        Plan::GrpRange gr;
-        gr.l0 = (int32_t)neworder.size();
-        gr.nl = (int32_t)(b - a);
-        gr.d = dop[cand[a]];
-        gr.no = deg(cand[a]);
-        pl.grp_range.push_back(gr);
-        for (size_t t = a; t < b; ++t) {
-          grouped[cand[t]] = 1;
-          neworder.push_back(pl.pt_user_of_int[cand[t]]);
-        }
-      }
-      a = b;
+    pl.grp_upat.clear();
+    for (GroupBuild &gb : groups) {
+      std::sort(gb.members.begin(), gb.members.end());  // locality order inside a group
+      Plan::GrpRange gr;
+      gr.l0 = (int32_t)neworder.size();
+      gr.nl = (int32_t)gb.members.size();
+      gr.d = gb.d;
+      gr.no = (int32_t)gb.upat.size();
+      gr.masked = gb.masked ? 1 : 0;
+      gr.upat0 = (int64_t)pl.grp_upat.size();
+      pl.grp_upat.insert(pl.grp_upat.end(), gb.upat.begin(), gb.upat.end());
+      pl.grp_range.push_back(gr);
+      for (int32_t i : gb.members) neworder.push_back(pl.pt_user_of_int[i]);
     }
     pl.M_grp = (int)neworder.size();
     for (int i = 0; i < M0; ++i)
-      if (!grouped[i]) neworder.push_back(pl.pt_user_of_int[i]);
+      if (group_of[i] < 0) neworder.push_back(pl.pt_user_of_int[i]);
     pl.pt_user_of_int.swap(neworder);
     for (int k = 0; k < M0; ++k) pl.pt_int_of_user[pl.pt_user_of_int[k]] = k;
   }
@@ -451,9 +584,23 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   {
     const int n_own = pl.n_pt;
     std::vector<int64_t> optr((size_t)n_own + 1, 0), pptr((size_t)n_own + 1, 0);
+    // group of every grouped landmark (masked groups pad their members to the union)
+    std::vector<int32_t> lm_grp((size_t)pl.M_grp, -1);
+    for (size_t gidx = 0; gidx < pl.grp_range.size(); ++gidx)
+      for (int l = pl.grp_range[gidx].l0; l < pl.grp_range[gidx].l0 + pl.grp_range[gidx].nl; ++l) lm_grp[l] = (int32_t)gidx;
+    auto masked_group = [&](int64_t pi) -> const Plan::GrpRange * {
+      if (pi >= pl.M_grp) return nullptr;
+      const Plan::GrpRange &gr = pl.grp_range[lm_grp[pi]];
+      return gr.masked ? &gr : nullptr;
+    };
     parallel_for(n_own, [&](int64_t a0, int64_t a1) {
       for (int64_t pi = a0; pi < a1; ++pi) {
         const int q = pl.pt_user_of_int[pi];
+        if (const Plan::GrpRange *gr = masked_group(pi)) {
+          optr[pi + 1] = gr->no;
+          pptr[pi + 1] = gr->d;
+          continue;
+        }
         optr[pi + 1] = uo_ptr[q + 1] - uo_ptr[q];
         if (pi < M) {
           int64_t np = 0;
@@ -479,9 +626,43 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     pl.lm_pair_ptr.assign(M + 1, 0);
     pl.pair_pose.resize((size_t)pptr[n_own]);
     pl.pair_lm.resize((size_t)pptr[n_own]);
+    pl.pair_pad.assign((size_t)pptr[n_own], 0);
     parallel_for(n_own, [&](int64_t a0, int64_t a1) {
       for (int64_t pi = a0; pi < a1; ++pi) {
         const int q = pl.pt_user_of_int[pi];
+        if (const Plan::GrpRange *gr = masked_group(pi)) {
+          // the union's slots in order; this landmark's observations are a subsequence
+          int64_t s = optr[pi], pw = pptr[pi] - 1, t = uo_ptr[q];
+          int32_t last = -1;
+          bool pose_seen = false;
+          for (int e = 0; e < gr->no; ++e, ++s) {
+            const uint64_t w = pl.grp_upat[gr->upat0 + e];
+            const int32_t ji = (int32_t)(w >> 32), cam = (int32_t)(uint32_t)w;
+            const bool have = t < uo_ptr[q + 1] && uo_rec[t].pose == ji && uo_rec[t].cam == cam;
+            pl.obs_idx[4 * s + 0] = cam;
+            pl.obs_idx[4 * s + 1] = ji;
+            pl.obs_idx[4 * s + 2] = (int32_t)pi;
+            pl.obs_idx[4 * s + 3] = -1;
+            pl.obs_uv[2 * s + 0] = have ? uo_rec[t].u : std::numeric_limits<double>::quiet_NaN();
+            pl.obs_uv[2 * s + 1] = have ? uo_rec[t].v : std::numeric_limits<double>::quiet_NaN();
+            if (ji < N) {
+              if (ji != last) {
+                ++pw;
+                pl.pair_pose[pw] = ji;
+                pl.pair_lm[pw] = (int32_t)pi;
+                pose_seen = false;
+              } else {
+                pl.obs_idx[4 * (s - 1) + 3] = -1;  // (the pair id sits on the pose's LAST slot)
+              }
+              pl.obs_idx[4 * s + 3] = (int32_t)pw;
+              pose_seen = pose_seen || have;
+              pl.pair_pad[pw] = pose_seen ? 0 : 1;
+            }
+            last = ji < N ? ji : -1;
+            if (have) ++t;
+          }
+          continue;
+        }
         int64_t s = optr[pi], pw = pptr[pi] - 1;
         int32_t last = -1;
         for (int64_t t = uo_ptr[q]; t < uo_ptr[q + 1]; ++t, ++s) {
@@ -513,6 +694,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       pl.lm_obs_ptr[i + 1] = optr[i + 1] - optr[i];
       pl.lm_pair_ptr[i + 1] = pptr[i + 1] - pptr[i];
     }
+    pl.n_pair_pad = 0;
+    for (uint8_t v : pl.pair_pad) pl.n_pair_pad += v;
   }
   for (int i = 0; i < M; ++i) {
     pl.lm_obs_ptr[i + 1] += pl.lm_obs_ptr[i];
@@ -747,7 +930,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           ld.pat0 = pat0;
           ld.apart0 = (int32_t)pl.n_apart2;
           ld.cost_idx = 0;  // set below, after the chunks are known
-          ld.pad_ = 0;
+          ld.pad_ = gr.masked;  // 1: padded slots (uv = NaN) and a dynamic last writer
           pl.n_apart2 += gr.d;
           if (ld.nl > 0) pl.lin_desc.push_back(ld);
         }
@@ -1019,12 +1202,17 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   // ---- k_lin_grp bookkeeping: cost-partial entry of each group piece (after the
   // chunks' entries), rows of Apart2 per pose ----
   {
+    // plain pieces first, masked pieces behind them: one launch of each k_lin_grp form
+    std::stable_partition(pl.lin_desc.begin(), pl.lin_desc.end(), [](const Plan::LinDesc &g) { return g.pad_ == 0; });
+    pl.n_lin_plain = 0;
+    for (auto &g : pl.lin_desc) pl.n_lin_plain += g.pad_ == 0;
     int32_t ci = (int32_t)pl.bchunk_lm.size() - 1;
     for (auto &g : pl.lin_desc) g.cost_idx = ci++;
     pl.pose_gpart_ptr.assign(N + 1, 0);
     if (!pl.lin_groups) {
       pl.n_apart2 = 0;
       pl.lin_desc.clear();
+      pl.n_lin_plain = 0;
     }
     for (auto &g : pl.lin_desc)
       for (int t = 0; t < g.d; ++t) pl.pose_gpart_ptr[pl.pair_pose[g.p0 + t] + 1]++;

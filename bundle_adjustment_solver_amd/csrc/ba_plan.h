@@ -158,7 +158,18 @@ struct Plan {
   // included), hence the identical set of d optimisable poses.
   int M_grp = 0;
   bool lin_groups = false;               // the groups are also linearised by k_lin_grp
-  struct GrpRange { int32_t l0, nl, d, no; };  // landmarks [l0, l0 + nl): d free poses, no observations each
+  // landmarks [l0, l0 + nl): d free poses, no pattern slots each.  masked: the pattern
+  // is the UNION of the members' patterns (grp_upat[upat0 .. upat0 + no): (pose << 32) |
+  // camera); a member's missing observations are padded slots with uv = NaN, its
+  // missing pairs zero W records
+  struct GrpRange {
+    int32_t l0, nl, d, no;
+    int32_t masked;
+    int64_t upat0;
+  };
+  std::vector<uint64_t> grp_upat;
+  std::vector<uint8_t> pair_pad;         // P: 1 = padded pair of a masked group (no observation)
+  int64_t n_pair_pad = 0;
   std::vector<GrpRange> grp_range;
   struct GrpDesc {                       // one k_schur_grp workgroup (64 bytes)
     int64_t p0;                          // first pair: pair(il, jj) = p0 + d * il + jj
@@ -170,9 +181,10 @@ struct Plan {
     int32_t l0, nl, d, no;               // landmarks, free poses, observations per landmark
     int32_t pat0;                        // first entry of the group's pattern in grp_pat
     int32_t apart0, cost_idx;            // first of its d rows of Apart2, its entry of lin_cost_part
-    int32_t pad_;
+    int32_t pad_;                        // 1 = piece of a masked (superset) group
   };
-  std::vector<LinDesc> lin_desc;
+  std::vector<LinDesc> lin_desc;         // plain pieces [0, n_lin_plain), then the masked ones (pad_ = 1)
+  int n_lin_plain = 0;
   std::vector<GrpDesc> grp32, grp64;     // d <= 5 / 6 <= d <= 10
   // pattern entry of observation slot oo: {pose (internal index), camera | jj << 16 |
   // optimisable pose << 29 | last writer of its pair << 30}

@@ -125,9 +125,12 @@ def test_ba_scene(seed=SEED_BASE + 1, pixel_sigma=0.0):
 
 
 def synthetic_ba_scene(n_pose, n_pt, window, stereo, seed, n_fixed=5,
-                       pixel_sigma=0.0, pose_noise=0.1, point_noise=0.5):
+                       pixel_sigma=0.0, pose_noise=0.1, point_noise=0.5, dropout=0.0):
     """Configs C2..C4: every landmark is seen by `window`
-    consecutive poses in every camera -> n_obs = n_pt * window * n_cam."""
+    consecutive poses in every camera -> n_obs = n_pt * window * n_cam.
+    dropout > 0 (config C4R): every observation is dropped independently with that
+    probability (occlusion / track loss), a landmark keeps at least two — the
+    observation patterns then differ from landmark to landmark."""
     rng = np.random.default_rng(seed)
     intr, T_cj = stereo_cameras(stereo)
     n_cam = intr.shape[0]
@@ -175,6 +178,12 @@ def synthetic_ba_scene(n_pose, n_pt, window, stereo, seed, n_fixed=5,
     uv = uv_all.reshape(-1, 2)
     if pixel_sigma > 0:
         uv = uv + rng.normal(0, pixel_sigma, uv.shape)
+    if dropout > 0:
+        keep = rng.uniform(size=lm.size) >= dropout
+        # (a landmark keeps its first two observations whatever the draw)
+        first_two = np.tile(np.arange(window * n_cam) < 2, n_pt)
+        keep |= first_two
+        lm, ci, pose, uv = lm[keep], ci[keep], pose[keep], uv[keep]
     order = np.lexsort((lm, ci, pose))
     T_wc_init = T_wc_true.copy()
     T_wc_init[n_fixed:, :3, 3] += rng.uniform(-pose_noise, pose_noise,
@@ -244,6 +253,10 @@ def dense_covisibility_scene(n_pose, n_pt, views, seed, n_fixed=5, pose_noise=0.
 
 # configurations OFF the headline's happy path (bench.py --config ...)
 OFFPATH = {
+    # C4 with per-observation dropout (p = 0.15): real visibility — occlusion, image
+    # borders, track loss — breaks the exact repetition of observation patterns that the
+    # covisibility groups of the headline scene rely on
+    "C4R": ("window_dropout", (1000, 500_000, 5, True, SEED_BASE + 4, 0.15)),
     # mono, windows of 20 poses: a landmark's 210 block pairs exceed the 128 register
     # slots of a super-run and its pose set the 10 poses of a covisibility group ->
     # everything goes through k_schur_partial's global triple list
@@ -270,6 +283,11 @@ def config_scene(name, scale=1.0, pixel_sigma=0.0, landmark_factor=1):
             return dense_covisibility_scene(max(20, int(round(n_pose * scale))),
                                             max(200, int(round(n_pt * scale))) * landmark_factor,
                                             views, seed, pixel_sigma=pixel_sigma)
+        if kind == "window_dropout":
+            n_pose, n_pt, window, stereo, seed, drop = par
+            return synthetic_ba_scene(max(window + 6, int(round(n_pose * scale))),
+                                      max(16, int(round(n_pt * scale))) * landmark_factor, window,
+                                      stereo, seed, pixel_sigma=pixel_sigma, dropout=drop)
         n_pose, n_pt, window, stereo, seed = par
         return synthetic_ba_scene(max(window + 6, int(round(n_pose * scale))),
                                   max(16, int(round(n_pt * scale))) * landmark_factor, window,

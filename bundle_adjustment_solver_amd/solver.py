@@ -479,6 +479,13 @@ class BaProblem:
         return dict(group_pieces=int(v[0]), group_observations=int(v[1]), chunks=int(v[2]),
                     pose_major_observations=int(v[3]))
 
+    def get_mask_info(self):
+        """Superset (masked) covisibility groups of this shard."""
+        v = (C.c_int64 * 4)()
+        check(self.lib.ba_get_mask_info(self.h, v), "ba_get_mask_info")
+        return dict(masked_pieces=int(v[0]), masked_landmarks=int(v[1]),
+                    padded_observation_slots=int(v[2]), padded_pairs=int(v[3]))
+
     def get_dropped_pivots(self, reset=False):
         """Non-positive pivots met by the reduced-system Cholesky since lm_begin
         (see include/ba_hip.h: where it differs from the reference's pivoted

@@ -254,6 +254,14 @@ int ba_get_schur_info(ba_handle *h, int64_t out8[8]);
  * pose-major list }. */
 int ba_get_lin_info(ba_handle *h, int64_t out4[4]);
 
+/* Superset ("masked") covisibility groups — landmarks of one pose span whose
+ * observation patterns differ (occlusion, image borders, track loss) share the UNION
+ * of their patterns; a member's missing observations are padded slots of weight 0, its
+ * missing pairs zero W records: out4 = { k_lin_grp pieces of masked groups, landmarks
+ * in masked groups, padded observation slots, padded (landmark, pose) pairs }.  The
+ * padding is internal: ba_num_pairs / ba_get_pairs do not show it. */
+int ba_get_mask_info(ba_handle *h, int64_t out4[4]);
+
 /* The reduced system is factorised by Cholesky WITHOUT pivoting; the
  * reference uses Eigen's diagonally pivoted LDLT with a pseudo-inverted D
  * (reference :905).  A non-positive pivot (<= 1e-300: a pose without

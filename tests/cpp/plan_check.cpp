@@ -2,6 +2,7 @@
 // tests/test_plan_invariants.py.  Scene: every landmark is seen by `win`
 // consecutive poses in `n_cam` cameras (the C2..C4 structure), plus a few
 // landmarks seen by many poses and a few never observed.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@ static int g_fail = 0;
 int main(int argc, char **argv) {
   const int n_pose = argc > 1 ? atoi(argv[1]) : 120, n_pt = argc > 2 ? atoi(argv[2]) : 30000;
   const int win = argc > 3 ? atoi(argv[3]) : 5, n_cam = argc > 4 ? atoi(argv[4]) : 2;
+  const int drop_pct = argc > 5 ? atoi(argv[5]) : 0;  // observations dropped pseudo-randomly (masked groups)
   std::vector<uint8_t> pf(n_pose, 0), qf(n_pt, 0);
   for (int k = 0; k < 3; ++k) pf[k] = 1;
   for (int q = 0; q < n_pt; q += 97) qf[q] = 1;
@@ -36,7 +38,10 @@ int main(int argc, char **argv) {
     int j0 = (int)((long long)q * (n_pose - win + 1) / n_pt), w = win;
     if (q % 4001 == 7) { j0 = 0; w = n_pose; }  // seen by every pose
     for (int j = j0; j < j0 + w; ++j)
-      for (int c = 0; c < n_cam; ++c) { oc.push_back(c); op.push_back(j); oq.push_back(q); uv.push_back(q); uv.push_back(j); }
+      for (int c = 0; c < n_cam; ++c) {
+        const unsigned hsh = (unsigned)(q * 2654435761u) ^ (unsigned)(j * 40503u + c * 977u);
+        if (drop_pct > 0 && !(j == j0 && c == 0) && (int)((hsh >> 7) % 100u) < drop_pct) continue;
+        oc.push_back(c); op.push_back(j); oq.push_back(q); uv.push_back(q); uv.push_back(j); }
   }
   ba::PlanInput in;
   in.n_cam = n_cam; in.n_pose = n_pose; in.pose_fixed = pf.data(); in.n_pt = n_pt; in.pt_fixed = qf.data();
@@ -57,7 +62,17 @@ int main(int argc, char **argv) {
     CHECK((k < pl.M) == (qf[q] == 0), "optimised landmarks must come first (k=%d)", k);
   }
   // ---- observation list: landmark-major, every pair id in range, last writer only ----
-  CHECK(pl.n_obs == in.n_obs, "observation count");
+  // (masked covisibility groups pad their members to the union pattern: padded slots
+  //  carry uv = NaN; the real observations are all there, each exactly once)
+  {
+    int64_t real = 0;
+    for (int64_t s2 = 0; s2 < pl.n_obs; ++s2) real += pl.obs_uv[2 * s2] == pl.obs_uv[2 * s2];
+    CHECK(real == in.n_obs && pl.n_obs >= in.n_obs, "observation count: %lld real of %lld slots, %lld given",
+          (long long)real, (long long)pl.n_obs, (long long)in.n_obs);
+    int64_t pad = 0;
+    for (uint8_t v : pl.pair_pad) pad += v;
+    CHECK(pad == pl.n_pair_pad && (pl.pair_pad.empty() || (int64_t)pl.pair_pad.size() == pl.P), "padded pair flags");
+  }
   for (int i = 0; i < pl.M; ++i) {
     std::set<int> poses;
     for (int64_t s = pl.lm_obs_ptr[i]; s < pl.lm_obs_ptr[i + 1]; ++s) {
@@ -177,13 +192,20 @@ int main(int argc, char **argv) {
     // last slot writes the pair
     {
       int nextl = 0;
-      for (const auto &gd : pl.lin_desc) {
+      long long n_masked_slots = 0;
+      // (plain pieces first, masked pieces behind them: the tiling is by landmark)
+      std::vector<ba::Plan::LinDesc> pieces(pl.lin_desc.begin(), pl.lin_desc.end());
+      for (size_t k = 0; k < pieces.size(); ++k)
+        CHECK((pieces[k].pad_ == 0) == ((int)k < pl.n_lin_plain), "plain pieces precede the masked ones");
+      std::sort(pieces.begin(), pieces.end(), [](const ba::Plan::LinDesc &x, const ba::Plan::LinDesc &y) { return x.l0 < y.l0; });
+      for (const auto &gd : pieces) {
         CHECK(gd.l0 == nextl && gd.nl >= 1, "k_lin_grp pieces tile [0, M_grp)");
         nextl = gd.l0 + gd.nl;
         CHECK(gd.no >= gd.d && gd.no >= 1 && gd.no <= ba::kGrpMaxObs && gd.o0 == pl.lm_obs_ptr[gd.l0] && gd.p0 == pl.lm_pair_ptr[gd.l0],
               "piece observation / pair base");
         CHECK(gd.nl <= ba::kLinGrpSteps * 4 * ba::lin_grp_nlw(gd.no) || getenv("BA_LIN_STEPS"), "piece size");
         CHECK(gd.pat0 >= 0 && (size_t)(gd.pat0 + gd.no) * 2 <= pl.grp_pat.size(), "group pattern range");
+        int pose_valid[ba::kGrpMaxPoses] = {0};
         for (int l = gd.l0; l < gd.l0 + gd.nl; ++l) {
           CHECK(pl.lm_obs_ptr[l + 1] - pl.lm_obs_ptr[l] == gd.no, "group landmark observation count");
           CHECK(pl.lm_pair_ptr[l + 1] - pl.lm_pair_ptr[l] == gd.d, "group landmark degree");
@@ -198,10 +220,24 @@ int main(int argc, char **argv) {
             const int64_t pair = pl.obs_idx[4 * s + 3];
             CHECK(lastw == (pair >= 0), "pattern last-writer flag");
             if (lastw) CHECK(pair == gd.p0 + (int64_t)gd.d * (l - gd.l0) + jj, "pattern pair id");
+            const bool have = pl.obs_uv[2 * s] == pl.obs_uv[2 * s];
+            if (!gd.pad_) CHECK(have, "a plain group has no padded slot");
+            if (opt && have) pose_valid[jj] = 1;
+            n_masked_slots += !have;
+          }
+          for (int jj = 0; jj < gd.d; ++jj) {
+            const int64_t pr = gd.p0 + (int64_t)gd.d * (l - gd.l0) + jj;
+            const bool pad = !pl.pair_pad.empty() && pl.pair_pad[pr];
+            CHECK(pad == !pose_valid[jj], "a pair is padded iff its pose has no valid slot in the landmark");
+            pose_valid[jj] = 0;
           }
         }
       }
       CHECK(nextl == (pl.lin_groups ? pl.M_grp : 0), "k_lin_grp pieces cover the grouped landmarks");
+      std::printf("masked groups: %d pieces of %zu, %lld padded slots, %lld padded pairs\n",
+                  (int)pl.lin_desc.size() - pl.n_lin_plain, pl.lin_desc.size(), n_masked_slots, (long long)pl.n_pair_pad);
+      if (drop_pct > 0 && !getenv("BA_NO_SUPERSET") && pl.lin_groups)
+        CHECK((int)pl.lin_desc.size() > pl.n_lin_plain && n_masked_slots > 0, "the dropout scene must produce masked groups");
     }
     for (int l = 0; l < pl.M; ++l) {
       CHECK(gcov[l] == want_piece[l], "landmark %d in %d group pieces", l, gcov[l]);

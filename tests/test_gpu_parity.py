@@ -1147,7 +1147,7 @@ def test_random_observation_patterns_match_oracle(seed, built):
     assert blockwise_relerr(W[key], oW[okey]) < RTOL_BLOCK
 
 
-@pytest.mark.parametrize("name,scale", [("W20", 0.1), ("DENSE1K", 0.06)])
+@pytest.mark.parametrize("name,scale", [("W20", 0.1), ("DENSE1K", 0.06), ("C4R", 0.04)])
 def test_off_path_configs_match_oracle(name, scale, built):
     """The two configurations bench.py measures OFF the headline's happy path,
     at a size the faithful oracle follows: 20-pose windows (every landmark goes
@@ -1156,11 +1156,62 @@ def test_off_path_configs_match_oracle(name, scale, built):
     pr = scenes.scaled_problem(scenes.config_scene(name, scale))
     g, o = _compare_solve(pr, iters=8, tol_par=1e-5)
     info = g.get_schur_info()
-    if name == "W20":
+    if name == "C4R":
+        assert g.get_mask_info()["masked_landmarks"] > 0.5 * g.M_global
+    elif name == "W20":
         assert info["grouped_landmarks"] == 0   # (a few landmarks near the fixed poses have
         #                                          < 16 free poses and still fit a super-run)
     else:
         assert g.get_dense_info()["fill"] > 0.9
+
+
+@pytest.mark.parametrize("kind", ["stereo", "mono", "stereo_noise"])
+def test_masked_superset_groups_match_oracle(kind, built, monkeypatch):
+    """Real visibility breaks the exact repetition of observation patterns: with 15-25 %
+    of the observations dropped at random the landmarks of a pose window share the
+    UNION of their patterns in a masked covisibility group (padded slots: uv = NaN,
+    weight 0; padded pairs: W = 0; the pair's last writer is its last VALID slot).
+    Blocks (A, a, C, b, W pair by pair — padded pairs are not shown), the reduced
+    system and the LM trajectory against the oracle; and against the library's own
+    exact-groups-only plan (BA_NO_SUPERSET=1) to 1e-11."""
+    stereo = kind != "mono"
+    sc = scenes.synthetic_ba_scene(40, 6000, 5 if stereo else 9, stereo, seed=41,
+                                   pixel_sigma=0.4 if kind == "stereo_noise" else 0.0,
+                                   dropout=0.15 if stereo else 0.25)
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    mi = g.get_mask_info()
+    assert mi["masked_landmarks"] > 0.5 * g.M_global and mi["padded_observation_slots"] > 0
+    assert g.get_schur_info()["grouped_landmarks"] > 0.9 * g.M_global
+    if stereo:
+        assert mi["padded_pairs"] > 0
+    lam, hub = 2.0, 1.0 if kind != "stereo_noise" else 0.004
+    o.linearize(hub); o.damp_invert(lam); o.schur()
+    g.stage_linearize(lam, hub); g.stage_schur()
+    for (a, b) in zip(g.get_A() + g.get_C(), o.get_A() + o.get_C()):
+        assert blockwise_relerr(a, b) < RTOL_BLOCK
+    pi, pj, W = g.get_pairs()
+    opi, opj, oW = o.get_pairs()
+    key, okey = np.lexsort((pj, pi)), np.lexsort((opj, opi))
+    assert pi.shape == opi.shape and (pi[key] == opi[okey]).all() and (pj[key] == opj[okey]).all()
+    assert blockwise_relerr(W[key], oW[okey]) < RTOL_BLOCK
+    S, rhs = g.get_S()
+    oS, orhs = o.get_S()
+    assert relerr(S, oS) < 1e-9 and relerr(rhs, orhs) < 1e-9
+    assert relerr(g.stage_cost(), o.cost()) < 1e-12
+    kw = dict(max_iter=12, thr_step=0, thr_cost=0, huber=hub)
+    rows, _ = g.solve(make_options(**kw))
+    orows, _ = o.solve(O.make_options(**kw))
+    assert_same_trajectory(rows, orows)
+    ang, dt, dX = north_star_errors(g, o)
+    assert ang <= RTOL_FINAL and dt <= RTOL_FINAL and dX <= RTOL_FINAL, (ang, dt, dX)
+    monkeypatch.setenv("BA_NO_SUPERSET", "1")
+    e = make_gpu(pr)
+    assert e.get_mask_info()["masked_landmarks"] == 0
+    erows, _ = e.solve(make_options(**kw))
+    for a, b in zip(rows, erows):
+        assert a.iteration_status == b.iteration_status
+        assert abs(a.trial_cost - b.trial_cost) <= 1e-11 * abs(b.trial_cost)
 
 
 def test_update_values_resolves_without_replanning(built):

@@ -39,6 +39,9 @@ def plan_check(tmp_path_factory):
     (["90", "2000", "37", "2"], {"BA_NO_GROUPS": "1"}),     # four pose groups per landmark, ten classes
     (["120", "30000", "5", "2"], {"BA_LIN_STEPS": "2"}),    # many k_lin_grp pieces per group
     (["120", "30000", "5", "2"], {"BA_NO_LINGRP": "1"}),    # groups for the Schur kernel only
+    (["120", "30000", "5", "2", "15"], {}),                 # 15 % of the observations dropped: superset (masked) groups
+    (["40", "3000", "9", "1", "25"], {}),                   # the same, mono with wide windows
+    (["120", "30000", "5", "2", "15"], {"BA_NO_SUPERSET": "1"}),  # ... with exact groups only
 ])
 def test_plan_invariants(plan_check, args, env):
     r = subprocess.run([plan_check] + args, env=dict(os.environ, **env),
