@@ -401,14 +401,30 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       std::vector<int32_t> members;   // preliminary landmark indices
       int d = 0;
       bool masked = false;
-      int32_t last_pose = 0;
+      int32_t first_pose = 0, last_pose = 0;  // span in user pose indices
     };
     std::vector<GroupBuild> groups;
     std::vector<int32_t> group_of(M0, -1);
-    static const bool no_superset_env = getenv("BA_NO_SUPERSET") && getenv("BA_NO_SUPERSET")[0] == '1';
+    const bool no_superset_env = getenv("BA_NO_SUPERSET") && getenv("BA_NO_SUPERSET")[0] == '1';
     const bool superset = pl.lin_groups && !no_superset_env;
-    auto first_pose = [&](int i) { return (int32_t)(pat[kp[i]] >> 32); };
-    auto last_pose = [&](int i) { return (int32_t)(pat[kp[i + 1] - 1] >> 32); };
+    // the pose SPAN of a landmark in USER pose indices (the registration order of the
+    // poses is normally the trajectory; the internal order puts the fixed poses last,
+    // which would throw every window that touches a fixed pose into one bucket)
+    std::vector<int32_t> span_lo(M0, 0), span_hi(M0, 0);
+    parallel_for(M0, [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; ++i) {
+        int32_t lo = INT32_MAX, hi = -1;
+        for (int64_t t = kp[i]; t < kp[i + 1]; ++t) {
+          const int32_t u = pl.pose_user_of_int[(size_t)(pat[t] >> 32)];
+          lo = std::min(lo, u);
+          hi = std::max(hi, u);
+        }
+        span_lo[i] = lo;
+        span_hi[i] = hi;
+      }
+    });
+    auto first_pose = [&](int i) { return span_lo[i]; };
+    auto last_pose = [&](int i) { return span_hi[i]; };
     // a member of a superset group must list its (pose, camera) entries in strictly
     // increasing order: the slots of the union are in that order, and the pair's last
     // WRITER (reference :826: the last inserted observation of a pose) is then the last
@@ -438,6 +454,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           GroupBuild gb;
           gb.upat.assign(pat.begin() + kp[cand[a]], pat.begin() + kp[cand[a] + 1]);
           gb.d = dop[cand[a]];
+          gb.first_pose = first_pose(cand[a]);
           gb.last_pose = last_pose(cand[a]);
           for (size_t t = a; t < b; ++t) {
             gb.members.push_back(cand[t]);
@@ -487,7 +504,8 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           GroupBuild gb;
           gb.upat = uni;
           gb.d = du;
-          gb.last_pose = (int32_t)(uni.back() >> 32);
+          gb.first_pose = first_pose(cand[a]);
+          gb.last_pose = last_pose(cand[a]);
           for (size_t t = a; t < b; ++t) {
             const int i = cand[t];
             if (has_dup(i)) continue;
@@ -505,7 +523,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       // leftovers join a group whose union contains their pattern
       std::vector<std::vector<int32_t>> by_first(in.n_pose + 1);
       for (size_t gidx = 0; gidx < groups.size(); ++gidx)
-        by_first[(size_t)(groups[gidx].upat.front() >> 32)].push_back((int32_t)gidx);
+        by_first[(size_t)groups[gidx].first_pose].push_back((int32_t)gidx);
       for (int i : cand) {
         if (group_of[i] >= 0 || has_dup(i)) continue;
         const int32_t f = first_pose(i), l = last_pose(i);
