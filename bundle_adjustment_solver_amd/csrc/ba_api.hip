@@ -653,10 +653,13 @@ int ba_finalize(ba_handle *h) {
       dd.n_flow = (int)order.size();
       dd.flow_gen = 0;
       if (h->upload(&dd.flow_order, order) || h->dalloc(&dd.flow_flags, (size_t)std::max(1, ncb)) ||
-          h->dalloc(&dd.flow_ticket, (size_t)1))
+          h->dalloc(&dd.flow_ticket, (size_t)1) || h->dalloc(&dd.fwd_flags, (size_t)std::max(1, ncb)) ||
+          h->dalloc(&dd.fwd_ticket, (size_t)1))
         return -1;
       HIP_TRY(hipMemset(dd.flow_flags, 0, (size_t)std::max(1, ncb) * sizeof(int)));
       HIP_TRY(hipMemset(dd.flow_ticket, 0, sizeof(int)));
+      HIP_TRY(hipMemset(dd.fwd_flags, 0, (size_t)std::max(1, ncb) * sizeof(int)));
+      HIP_TRY(hipMemset(dd.fwd_ticket, 0, sizeof(int)));
     }
     HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
     // tiles (re)initialised per iteration: factor pattern + diagonal + rhs row

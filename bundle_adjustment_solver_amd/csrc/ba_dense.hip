@@ -269,6 +269,13 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
       if (ni > 0)                                                                           \
         BA_LAUNCH(K_CHOL_TRSM, NS::k_chol_trsm, dim3(ni), dim3(NS::NP * 64), s, L, ld,      \
                   row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);                       \
+    } else if (flow && dd.fwd_flags) {                                                      \
+      /* factorisation + TRSM and the updates that consume them: ONE dataflow launch */     \
+      const int tg0f = sc.tgt_ptr[l], ngf = sc.tgt_ptr[l + 1] - tg0f;                       \
+      BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_level_flow, dim3(nt + ngf), dim3(256), s, L,   \
+                ld, npad, t0, nt, tg0f, ngf, dd.row_desc, dd.rows, Ldiag, dd.tgt_desc,      \
+                dd.src_t, done, bad, dd.fwd_flags, dd.fwd_ticket, gen_now);                 \
+      continue;                                                                             \
     } else {                                                                                \
       BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_diag_trsm, dim3(nt), dim3(256), s, L, ld,      \
                 npad, t0, dd.row_desc, dd.rows, Ldiag, done, bad);                              \
@@ -290,7 +297,7 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
   if (flow && n_back > 0) {                                                                 \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow, dim3(n_back), dim3(256), s, L, ld, npad,   \
               dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, x,    \
-              dd.col_x, done, dd.flow_flags, dd.flow_ticket, ++dd.flow_gen, bad);           \
+              dd.col_x, done, dd.flow_flags, dd.flow_ticket, gen_now, bad);                 \
   } else                                                                                    \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
@@ -357,6 +364,7 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   const int n_back = back_t_end;
   const bool flow = dd.want_flow && dd.flow_ok && dd.flow_order && dd.n_flow == n_back &&
                     dd.flow_tail_t0 == back_t_end && !fused;
+  const int gen_now = ++dd.flow_gen;  // generation number of this solve (flags are never reset)
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

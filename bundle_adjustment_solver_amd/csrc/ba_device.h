@@ -279,6 +279,9 @@ struct DenseDev {
   // dataflow backward sweep (k_chol_back_flow): tile positions top level first, one flag
   // per tile, the ticket counter; flow_gen = generation number of the next solve (host)
   int *flow_order = nullptr, *flow_flags = nullptr, *flow_ticket = nullptr;
+  // forward sweep, one dataflow launch per level (k_chol_level_flow): one flag per tile
+  // ("factorised, row tiles solved"), the ticket counter
+  int *fwd_flags = nullptr, *fwd_ticket = nullptr;
   int n_flow = 0, flow_tail_t0 = 0;
   mutable int flow_gen = 0;
   bool flow_ok = true;  // false while a hipGraph is captured / replayed (the generation is a kernel argument)

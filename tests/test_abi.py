@@ -88,3 +88,31 @@ def test_partition_points_host_only(built):
         pr["obs_pose"].ctypes.data_as(_lib._I32),
         bad.ctypes.data_as(_lib._I32), 2, owner.ctypes.data_as(_lib._I32))
     assert rc < 0 and b"out of range" in lib.ba_last_error()
+
+
+def test_dataflow_sweep_uses_sc1_hand_offs(tmp_path):
+    """k_chol_back_flow (csrc/ba_dense_tile.inc) hands x from workgroup to workgroup
+    inside ONE launch with relaxed agent-scope atomics and `s_waitcnt vmcnt(0)` instead
+    of release / acquire fences.  That is correct only while those accesses compile to
+    sc1 loads / stores (they bypass the non-coherent cache levels) — a property of the
+    compiler and the target, not of the memory model: the generated code is checked."""
+    import subprocess
+    csrc = os.path.join(ROOT, "bundle_adjustment_solver_amd", "csrc")
+    asm = str(tmp_path / "ba_dense.s")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+                    "-ffp-contract=off", "--cuda-device-only", "-S",
+                    os.path.join(csrc, "ba_dense.hip"), "-o", asm], check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    text = open(asm).read()
+    seen = 0
+    for nb in ("nb32", "nb64"):
+        start = text.index("%s16k_chol_back_flow" % nb)
+        start = text.index(":\n", start)
+        body = text[start:text.index("s_endpgm", start)]
+        loads = [l for l in body.splitlines() if "global_load" in l and "sc1" in l]
+        stores = [l for l in body.splitlines() if "global_store" in l and "sc1" in l]
+        assert len(loads) >= 3 and len(stores) >= 2, (nb, len(loads), len(stores))
+        assert "s_waitcnt vmcnt(0)" in body
+        assert "buffer_wbl2" not in body and "buffer_inv" not in body   # no cache-wide fences
+        seen += 1
+    assert seen == 2
