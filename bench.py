@@ -61,7 +61,7 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
-PMC_SUMMARY = {"C4": "profiles/r02_c4_pmc_fetch_write_v6.txt"}
+PMC_SUMMARY = {"C4": "profiles/r03_c4_pmc_fetch_write_v1.txt"}
 
 
 def pmc_traffic(kernel, config):
@@ -78,9 +78,12 @@ def pmc_traffic(kernel, config):
     vals = {}
     for line in open(path):
         f = line.split()
-        if len(f) >= 4 and f[0].split("<")[0] == kernel and f[1] in (
-                "FETCH_SIZE", "WRITE_SIZE"):
-            vals[f[1]] = float(f[3])
+        # "k_lin_grp<true, false> FETCH_SIZE 5 45628.2": the counter name follows the
+        # (possibly templated) kernel name, the mean per dispatch is the last field
+        if len(f) >= 4 and f[0].split("<")[0] == kernel:
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                if c in f:
+                    vals[c] = float(f[-1])
     if len(vals) != 2:
         return None, None
     return ((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
@@ -579,8 +582,9 @@ def main():
         # N x M grids of 6x3 / 3x6 blocks, re-zeroed by ResetStorageMatrices
         # every iteration, reference :343-379).  Runnable at C1 (21 MB) and C2
         # (5.6 GB) only.
-        result["cpu_baseline"]["dense_faithful"] = dense_faithful_baseline(
-            O, scenes, args.config, pr if args.scale == 1.0 else None, args.huber)
+        if args.config in DENSE_GRID_GB:   # (the BASELINE configs; not the off-path ones)
+            result["cpu_baseline"]["dense_faithful"] = dense_faithful_baseline(
+                O, scenes, args.config, pr if args.scale == 1.0 else None, args.huber)
 
     if rank == 0:
         print(json.dumps(result))
