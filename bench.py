@@ -235,6 +235,10 @@ def main():
     ap.add_argument("--arena-mb", type=float, default=0.0,
                     help="size of each of the two arenas with --stream (default: the largest "
                          "chunk + 2 %%)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="with one rank: still run the N > 1 code path (process group, RCCL "
+                         "exchange from C++, separate control kernel, final landmark gather) — "
+                         "what a one-GPU box can rehearse of the multi-GPU bench with real RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -271,15 +275,17 @@ def main():
         local_rank %= max(1, torch.cuda.device_count())
     if torch.cuda.device_count() > 0:   # (without a GPU ba_create below fails loudly: no CPU path)
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_exchange
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if rehearsal:
             dist.init_process_group(backend, rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
 
-    if world > 1:
+    if sharded:
         dist.barrier()   # rank 0 has finished build()
     from bundle_adjustment_solver_amd import scenes
     from bundle_adjustment_solver_amd._lib import make_options
@@ -302,7 +308,7 @@ def main():
     p.set_observations(pr["obs_cam"], pr["obs_pose"], pr["obs_pt"],
                        pr["obs_uv"])
     keep = []
-    if world > 1:
+    if sharded:
         p.set_shard(rank, world)   # (the handle keeps its own stream: the exchange
         #                            hook is told which one, see sharding.TorchExchange)
     t_fin = time.time()
@@ -310,7 +316,7 @@ def main():
     t_fin = time.time() - t_fin
     n_ranks_seen = 1
     exchange = "none"
-    if world > 1:
+    if sharded:
         # the per-iteration collectives: RCCL from C++ inside the library (no Python
         # between the kernels); BA_BENCH_EXCHANGE=torch keeps them in torch.distributed
         # (a Python callback twice per iteration), which is also what a gloo rehearsal
@@ -336,7 +342,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -349,7 +355,7 @@ def main():
     p.lm_sync()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         te = torch.tensor([elapsed], dtype=torch.float64,
                           device="cpu" if rehearsal else "cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -586,9 +592,17 @@ def main():
             result["cpu_baseline"]["dense_faithful"] = dense_faithful_baseline(
                 O, scenes, args.config, pr if args.scale == 1.0 else None, args.huber)
 
+    if sharded:
+        # the end of a sharded Solve: every rank gathers every landmark (reference
+        # :1018-1022 writes back all of them); timed apart from the iterations
+        t_g = time.perf_counter()
+        p.gather_points()
+        Xall, owned = p.get_points()
+        result["gather_points_ms"] = (time.perf_counter() - t_g) * 1e3
+        assert bool(owned.all())
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

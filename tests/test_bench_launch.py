@@ -88,3 +88,24 @@ def test_plain_python_gpus2_rehearsal_prints_one_json_line(built):
     assert w["scaling"] == "weak" and w["n_ranks_seen"] == 2
     assert w["config"]["n_observations"] == 2 * a["config"]["n_observations"]
     assert w["config"]["n_opt_poses"] == a["config"]["n_opt_poses"]
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_exchange_path_of_the_bench(built):
+    """What a one-GPU box can run of the multi-GPU bench with REAL RCCL: one rank,
+    `nccl` process group, the library's own RCCL communicator (ba_rccl_*, hook called
+    from C++), the sharded iteration (separate control kernel, non-direct
+    k_schur_final + k_scatter) and the final landmark gather — same trajectory as the
+    plain single-GPU run of the same problem."""
+    common = ["--gpus", "1", "--scale", "0.05", "--config", "C3", "--steps", "6", "--warmup", "2",
+              "--no-cpu-baseline", "--no-roofline"]
+    plain = run_bench(common)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    forced = run_bench(common + ["--force-exchange"])
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    a, b = json_lines(plain.stdout), json_lines(forced.stdout)
+    assert len(a) == 1 and len(b) == 1
+    a, b = a[0], b[0]
+    assert "RCCL all-reduce issued by libba_hip.so" in b["config"]["exchange"]
+    assert b["n_ranks_seen"] == 1 and "gather_points_ms" in b
+    assert abs(a["final_cost"] - b["final_cost"]) <= 1e-9 * abs(a["final_cost"])
