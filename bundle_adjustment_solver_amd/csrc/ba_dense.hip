@@ -274,7 +274,8 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
       const int tg0f = sc.tgt_ptr[l], ngf = sc.tgt_ptr[l + 1] - tg0f;                       \
       BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_level_flow, dim3(nt + ngf), dim3(256), s, L,   \
                 ld, npad, t0, nt, tg0f, ngf, dd.row_desc, dd.rows, Ldiag, dd.tgt_desc,      \
-                dd.src_t, done, bad, dd.fwd_flags, dd.fwd_ticket, gen_now);                 \
+                dd.src_t, done, bad, dd.fwd_flags,                                          \
+                (nt + ngf <= kFlowResident && !dd.force_ticket) ? nullptr : dd.fwd_ticket, gen_now); \
       continue;                                                                             \
     } else {                                                                                \
       BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_diag_trsm, dim3(nt), dim3(256), s, L, ld,      \
@@ -297,13 +298,19 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
   if (flow && n_back > 0) {                                                                 \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow, dim3(n_back), dim3(256), s, L, ld, npad,   \
               dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, x,    \
-              dd.col_x, done, dd.flow_flags, dd.flow_ticket, gen_now, bad);                 \
+              dd.col_x, done, dd.flow_flags,                                                \
+              (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad); \
   } else                                                                                    \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back, dim3(nt), dim3(256), s, L, ld, npad, t0,        \
               dd.back_desc, dd.rows, Ldiag, dd.xc, x, dd.col_x, done);                      \
   }
+
+// Workgroups of a dataflow launch that are certainly resident at once on the part (256
+// CUs x 2 workgroups of 256 threads at the kernels' register budgets, with a margin):
+// up to here the role is the block index, beyond it a ticket (ba_dense_tile.inc).
+constexpr int kFlowResident = 448;
 
 // Levels handed to k_chol_tail (the last ones, together 64 or 96 columns, at least two).
 static int dense_tail_levels(const DenseSchedule &sc, const DenseDev &dd, bool fused, int *cols_out) {

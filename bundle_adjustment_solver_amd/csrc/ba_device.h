@@ -286,6 +286,7 @@ struct DenseDev {
   mutable int flow_gen = 0;
   bool flow_ok = true;  // false while a hipGraph is captured / replayed (the generation is a kernel argument)
   bool want_flow = true;
+  bool force_ticket = false;  // BA_DENSE_TICKET=1: tickets even when the grid is resident (test knob)
   // BA_DENSE_FUSED / BA_DENSE_SPLIT / BA_DENSE_TAIL as found when the schedule was uploaded
   bool want_fused = false, want_split = false, want_tail = true;
   void read_env() {
@@ -295,6 +296,8 @@ struct DenseDev {
     want_tail = !(t && t[0] == '0');
     const char *fl = getenv("BA_DENSE_FLOW");
     want_flow = !(fl && fl[0] == '0');
+    const char *tk = getenv("BA_DENSE_TICKET");
+    force_ticket = tk && tk[0] == '1';
   }
 };
 struct DenseSchedule;

@@ -365,15 +365,19 @@ def test_tail_workgroup_matches_the_level_path(built):
 
 def test_one_stream_iteration_and_dataflow_sweep_equal_their_fallbacks(built):
     """The LM loop of a grouped scene runs on ONE stream (tile reset as a role of
-    k_backsub_update, pose-side sums as workgroups of k_scalars) and its backward
-    sweep is ONE dataflow launch (ticket order, per-tile flags); BA_FORCE_SIDE=1
-    (side stream with fork / join) and BA_DENSE_FLOW=0 (one launch per level) are
-    the paths every other problem takes: same arithmetic in the same order, so the
-    trajectories must agree bit for bit, iteration by iteration."""
+    k_backsub_update, pose-side sums as workgroups of k_scalars); the forward sweep of
+    its reduced solve is ONE dataflow launch per level (k_chol_level_flow) and the
+    backward sweep ONE dataflow launch (per-tile flags; roles from the block index when
+    the grid is resident, from tickets otherwise: BA_DENSE_TICKET=1 forces tickets);
+    BA_FORCE_SIDE=1 (side stream with fork / join) and BA_DENSE_FLOW=0 (separate
+    diag_trsm / update launches, one backward launch per level) are the paths every
+    other problem takes: same arithmetic in the same order, so the trajectories must
+    agree bit for bit, iteration by iteration."""
     import os
     pr = scenes.scaled_problem(scenes.synthetic_ba_scene(150, 9000, 5, True, seed=33, pixel_sigma=0.3))
     runs = []
-    for env in ({}, {"BA_FORCE_SIDE": "1"}, {"BA_DENSE_FLOW": "0"}, {"BA_FORCE_SIDE": "1", "BA_DENSE_FLOW": "0"}):
+    for env in ({}, {"BA_FORCE_SIDE": "1"}, {"BA_DENSE_FLOW": "0"}, {"BA_FORCE_SIDE": "1", "BA_DENSE_FLOW": "0"},
+                {"BA_DENSE_TICKET": "1"}):
         for k, v in env.items():
             os.environ[k] = v
         try:
@@ -386,6 +390,7 @@ def test_one_stream_iteration_and_dataflow_sweep_equal_their_fallbacks(built):
                      g.get_points()[0].copy()))
         if not env:
             assert g.get_lin_info()["pose_major_observations"] == 0 and g.get_lin_info()["chunks"] == 0
+        assert g.get_dropped_pivots() == 0
     assert len(runs[0][0]) == 10
     for other in runs[1:]:
         assert other[0] == runs[0][0]
