@@ -212,6 +212,56 @@ __device__ __forceinline__ double rsq_refined(double m) {
   const double e = fma(-(m * y), y, 1.0);
   return fma(y * e, fma(0.375, e, 0.5), y);
 }
+// One 4-column block step of the short-chain factorisation: from the diagonal tile's
+// register gk (= G[r][c0 + q]) the A operand of the Y products (Ltilde^-1 on the lanes
+// r < 4), the reciprocal pivot rq and p^-1/2 (sck) of this lane's column c0 + q; `bad`
+// collects non-positive minors (wave-uniform).
+struct BlockStep {
+  double aop1, rq, sck;
+};
+__device__ __forceinline__ BlockStep tile16_block_step(const double gk, const int c0, const int r, const int q,
+                                                       const double b0, const double b1, const double b2,
+                                                       const double b3, bool &bad) {
+  // diagonal block, lower part: D[i][k] lives in lane (c0 + i, k)
+  const double d00 = readlane_f64(gk, c0 + 0);
+  const double w10 = readlane_f64(gk, c0 + 1), d11 = readlane_f64(gk, c0 + 1 + 16);
+  const double w20 = readlane_f64(gk, c0 + 2), d21 = readlane_f64(gk, c0 + 2 + 16),
+               d22 = readlane_f64(gk, c0 + 2 + 32);
+  const double w30 = readlane_f64(gk, c0 + 3), d31 = readlane_f64(gk, c0 + 3 + 16),
+               d32 = readlane_f64(gk, c0 + 3 + 32), d33 = readlane_f64(gk, c0 + 3 + 48);
+  // Bareiss: e = M1 S1, f = M2 S2, h = M3 S3 (S_k: Schur complement after k pivots)
+  const double M1 = d00;
+  const double q1 = rsq_refined(M1), i1 = q1 * q1;
+  const double e11 = fma(M1, d11, -(w10 * w10)), e21 = fma(M1, d21, -(w20 * w10)),
+               e31 = fma(M1, d31, -(w30 * w10)), e22 = fma(M1, d22, -(w20 * w20)),
+               e32 = fma(M1, d32, -(w30 * w20)), e33 = fma(M1, d33, -(w30 * w30));
+  const double M2 = e11;
+  const double q2 = rsq_refined(M2), i2 = q2 * q2;
+  const double f22 = fma(M2, e22, -(e21 * e21)) * i1, f32 = fma(M2, e32, -(e31 * e21)) * i1,
+               f33 = fma(M2, e33, -(e31 * e31)) * i1;
+  const double M3 = f22;
+  const double q3 = rsq_refined(M3), i3 = q3 * q3;
+  const double M4 = fma(M3, f33, -(f32 * f32)) * i2;
+  const double q4 = rsq_refined(M4), i4 = q4 * q4;
+  // the pivots p_k = M_(k+1) / M_k are positive iff the leading minors are: all must
+  // be safely positive (NaN fails too; a product of four tiny pivots that underflows
+  // takes the slow path as well, which is merely slower)
+  bad |= !((M1 > 1e-280) & (M2 > 1e-280) & (M3 > 1e-280) & (M4 > 1e-280));
+  const double l10 = w10 * i1, l20 = w20 * i1, l30 = w30 * i1, l21 = e21 * i2, l31 = e31 * i2,
+               l32 = f32 * i3;
+  // column q of Ltilde^-1 (rows 0..3), then this lane's row r (lanes r < 4 feed the MFMA)
+  const double x0 = b0;
+  const double x1 = fma(-l10, x0, b1);
+  const double x2 = fma(-l21, x1, fma(-l20, x0, b2));
+  const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, b3)));
+  BlockStep o;
+  o.aop1 = selb(r < 4, sel4b(r, x0, x1, x2, x3), 0.0);
+  // reciprocal pivots and their square roots for this lane's column c0 + q
+  o.rq = sel4b(q, i1, M1 * i2, M2 * i3, M3 * i4);
+  o.sck = sel4b(q, q1, M1 * q1 * q2, M2 * q2 * q3, M3 * q3 * q4);
+  return o;
+}
+
 __device__ __forceinline__ int tile16_potrf_inv2(double g[4], int lane, double &dinv) {
   const int r = lane & 15, q = lane >> 4;
   const double g_in[4] = {g[0], g[1], g[2], g[3]};
@@ -220,56 +270,22 @@ __device__ __forceinline__ int tile16_potrf_inv2(double g[4], int lane, double &
                b3 = q == 3 ? 1.0 : 0.0;
   double sc[4];  // p^-1/2 of this lane's column of every block
   bool bad = false;
+  const v4f64 zero4 = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
     const int c0 = 4 * kb;
-    // diagonal block, lower part: D[i][k] lives in lane (c0 + i, k)
-    const double d00 = readlane_f64(g[kb], c0 + 0);
-    const double w10 = readlane_f64(g[kb], c0 + 1), d11 = readlane_f64(g[kb], c0 + 1 + 16);
-    const double w20 = readlane_f64(g[kb], c0 + 2), d21 = readlane_f64(g[kb], c0 + 2 + 16),
-                 d22 = readlane_f64(g[kb], c0 + 2 + 32);
-    const double w30 = readlane_f64(g[kb], c0 + 3), d31 = readlane_f64(g[kb], c0 + 3 + 16),
-                 d32 = readlane_f64(g[kb], c0 + 3 + 32), d33 = readlane_f64(g[kb], c0 + 3 + 48);
-    // Bareiss: e = M1 S1, f = M2 S2, h = M3 S3 (S_k: Schur complement after k pivots)
-    const double M1 = d00;
-    const double q1 = rsq_refined(M1), i1 = q1 * q1;
-    const double e11 = fma(M1, d11, -(w10 * w10)), e21 = fma(M1, d21, -(w20 * w10)),
-                 e31 = fma(M1, d31, -(w30 * w10)), e22 = fma(M1, d22, -(w20 * w20)),
-                 e32 = fma(M1, d32, -(w30 * w20)), e33 = fma(M1, d33, -(w30 * w30));
-    const double M2 = e11;
-    const double q2 = rsq_refined(M2), i2 = q2 * q2;
-    const double f22 = fma(M2, e22, -(e21 * e21)) * i1, f32 = fma(M2, e32, -(e31 * e21)) * i1,
-                 f33 = fma(M2, e33, -(e31 * e31)) * i1;
-    const double M3 = f22;
-    const double q3 = rsq_refined(M3), i3 = q3 * q3;
-    const double M4 = fma(M3, f33, -(f32 * f32)) * i2;
-    const double q4 = rsq_refined(M4), i4 = q4 * q4;
-    // the pivots p_k = M_(k+1) / M_k are positive iff the leading minors are: all must
-    // be safely positive (NaN fails too; a product of four tiny pivots that underflows
-    // takes the slow path as well, which is merely slower)
-    bad |= !((M1 > 1e-280) & (M2 > 1e-280) & (M3 > 1e-280) & (M4 > 1e-280));
-    const double l10 = w10 * i1, l20 = w20 * i1, l30 = w30 * i1, l21 = e21 * i2, l31 = e31 * i2,
-                 l32 = f32 * i3;
-    // column q of Ltilde^-1 (rows 0..3), then this lane's row r (lanes r < 4 feed the MFMA)
-    const double x0 = b0;
-    const double x1 = fma(-l10, x0, b1);
-    const double x2 = fma(-l21, x1, fma(-l20, x0, b2));
-    const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, b3)));
-    const double aop1 = selb(r < 4, sel4b(r, x0, x1, x2, x3), 0.0);
+    const BlockStep bs = tile16_block_step(g[kb], c0, r, q, b0, b1, b2, b3, bad);
     const int rb = r - c0;  // 0..3 inside the block
     const bool inb = rb >= 0 && rb < 4;
     const double idr = selb(inb & (rb == q), 1.0, 0.0);
-    const v4f64 zero4 = (v4f64){0.0, 0.0, 0.0, 0.0};
     // Y[r][q] = sum_k P[r][k] Ltilde^-T[k][q]  (rows below the block: L sqrt(d); rows above
     // it: the folded inverse, same transform);  yu = row rb of Ltilde^-T for the block rows
-    const double ya = __builtin_amdgcn_mfma_f64_16x16x4f64(aop1, g[kb], zero4, 0, 0, 0)[0];
-    const double yu = __builtin_amdgcn_mfma_f64_16x16x4f64(aop1, idr, zero4, 0, 0, 0)[0];
-    // reciprocal pivots and their square roots for this lane's column c0 + q
-    const double rq = sel4b(q, i1, M1 * i2, M2 * i3, M3 * i4);
-    sc[kb] = sel4b(q, q1, M1 * q1 * q2, M2 * q2 * q3, M3 * q3 * q4);
+    const double ya = __builtin_amdgcn_mfma_f64_16x16x4f64(bs.aop1, g[kb], zero4, 0, 0, 0)[0];
+    const double yu = __builtin_amdgcn_mfma_f64_16x16x4f64(bs.aop1, idr, zero4, 0, 0, 0)[0];
+    sc[kb] = bs.sck;
     g[kb] = selb(inb & (q > rb), yu, ya);
     if (kb < 3) {
-      const double aop = selb(r > c0 + 3, -ya * rq, 0.0);
+      const double aop = selb(r > c0 + 3, -ya * bs.rq, 0.0);
       const double bop = selb(inb, selb(q >= rb, yu, 0.0), ya);
       v4f64 acc = (v4f64){g[0], g[1], g[2], g[3]};
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
@@ -291,6 +307,109 @@ __device__ __forceinline__ int tile16_potrf_inv2(double g[4], int lane, double &
   for (int j = 0; j < 4; ++j) {
     g[j] *= sc[j];
     dinv = selb(r == 4 * j + q, sc[j], dinv);
+  }
+  return 0;
+}
+
+// ---- a 32x32 SPD tile by ONE wave: three 16x16 register tiles ---------------------
+// g00 / g11: diagonal tiles in the folded layout above (lower = A, strict upper = 0 ->
+// L^-T of THAT 16x16 tile); g10: the full off-diagonal tile, lane (r, q) reg j =
+// A[16 + r][4 j + q].  Eight block steps of the short chain in a row: the first four
+// also carry g10 (its Y product is a third MFMA with the same A operand) and update all
+// three tiles (rank-4 MFMAs: the A operand of a product is indexed by the TARGET column,
+// the B operand by the row); the last four are tile16_potrf_inv2's on g11.  Replaces, for
+// 32-column tiles, factor_tile_lds' potrf -> barrier -> TRSM -> barrier -> SYRK -> barrier
+// -> potrf: no barrier, no LDS round trip, one wave.  Returns non-zero (wave-uniform)
+// when a minor is not safely positive: the tiles are then untouched and the caller takes
+// the first path, which keeps the zeroed-column semantics.
+__device__ __forceinline__ int tile32_potrf_inv(double g00[4], double g10[4], double g11[4], int lane,
+                                                double &dinv0, double &dinv1) {
+  const int r = lane & 15, q = lane >> 4;
+  const double in00[4] = {g00[0], g00[1], g00[2], g00[3]}, in10[4] = {g10[0], g10[1], g10[2], g10[3]},
+               in11[4] = {g11[0], g11[1], g11[2], g11[3]};
+  const double b0 = q == 0 ? 1.0 : 0.0, b1 = q == 1 ? 1.0 : 0.0, b2 = q == 2 ? 1.0 : 0.0,
+               b3 = q == 3 ? 1.0 : 0.0;
+  double sc0[4], sc1[4];
+  bool bad = false;
+  const v4f64 zero4 = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {  // columns 0 .. 15
+    const int c0 = 4 * kb;
+    const BlockStep bs = tile16_block_step(g00[kb], c0, r, q, b0, b1, b2, b3, bad);
+    const int rb = r - c0;
+    const bool inb = rb >= 0 && rb < 4;
+    const double idr = selb(inb & (rb == q), 1.0, 0.0);
+    const double ya = __builtin_amdgcn_mfma_f64_16x16x4f64(bs.aop1, g00[kb], zero4, 0, 0, 0)[0];
+    const double yu = __builtin_amdgcn_mfma_f64_16x16x4f64(bs.aop1, idr, zero4, 0, 0, 0)[0];
+    const double y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bs.aop1, g10[kb], zero4, 0, 0, 0)[0];
+    sc0[kb] = bs.sck;
+    g00[kb] = selb(inb & (q > rb), yu, ya);
+    g10[kb] = y1;
+    // trailing columns of the first tile column (targets in g00 and g10): A operand by
+    // target column = the rows of g00 below the block
+    if (kb < 3) {
+      const double aop = selb(r > c0 + 3, -ya * bs.rq, 0.0);
+      const double bop = selb(inb, selb(q >= rb, yu, 0.0), ya);
+      v4f64 acc = (v4f64){g00[0], g00[1], g00[2], g00[3]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+      v4f64 acc1 = (v4f64){g10[0], g10[1], g10[2], g10[3]};
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, y1, acc1, 0, 0, 0);
+#pragma unroll
+      for (int j = kb + 1; j < 4; ++j) {
+        const int c = 4 * j + q;
+        g00[j] = selb((r > c0 + 3) & (c > r), 0.0, acc[j]);
+        g10[j] = acc1[j];
+      }
+    }
+    // the second diagonal tile: target column = a row of g10 (all of them lie below the block)
+    {
+      v4f64 acc2 = (v4f64){g11[0], g11[1], g11[2], g11[3]};
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-y1 * bs.rq, y1, acc2, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g11[j] = selb(4 * j + q > r, 0.0, acc2[j]);  // (its folded identity rows are not active yet)
+    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {  // columns 16 .. 31: the second diagonal tile alone
+    const int c0 = 4 * kb;
+    const BlockStep bs = tile16_block_step(g11[kb], c0, r, q, b0, b1, b2, b3, bad);
+    const int rb = r - c0;
+    const bool inb = rb >= 0 && rb < 4;
+    const double idr = selb(inb & (rb == q), 1.0, 0.0);
+    const double ya = __builtin_amdgcn_mfma_f64_16x16x4f64(bs.aop1, g11[kb], zero4, 0, 0, 0)[0];
+    const double yu = __builtin_amdgcn_mfma_f64_16x16x4f64(bs.aop1, idr, zero4, 0, 0, 0)[0];
+    sc1[kb] = bs.sck;
+    g11[kb] = selb(inb & (q > rb), yu, ya);
+    if (kb < 3) {
+      const double aop = selb(r > c0 + 3, -ya * bs.rq, 0.0);
+      const double bop = selb(inb, selb(q >= rb, yu, 0.0), ya);
+      v4f64 acc = (v4f64){g11[0], g11[1], g11[2], g11[3]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+#pragma unroll
+      for (int j = kb + 1; j < 4; ++j) {
+        const int c = 4 * j + q;
+        g11[j] = selb((r > c0 + 3) & (c > r), 0.0, acc[j]);
+      }
+    }
+  }
+  if (bad) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g00[j] = in00[j];
+      g10[j] = in10[j];
+      g11[j] = in11[j];
+    }
+    return 1;
+  }
+  dinv0 = 0.0;
+  dinv1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    g00[j] *= sc0[j];
+    g10[j] *= sc0[j];
+    g11[j] *= sc1[j];
+    dinv0 = selb(r == 4 * j + q, sc0[j], dinv0);
+    dinv1 = selb(r == 4 * j + q, sc1[j], dinv1);
   }
   return 0;
 }

@@ -66,6 +66,120 @@ __global__ __launch_bounds__(64) void k_bench(const double *A, double *out, long
   }
 }
 
+// ---- the 32x32 one-wave routine ----
+__global__ __launch_bounds__(64) void k_bench32(const double *A, double *out, long long *cyc, int reps) {
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  double a00[4], a10[4], a11[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * j + q;
+    a00[j] = (r >= c) ? A[r * 32 + c] : 0.0;
+    a10[j] = A[(16 + r) * 32 + c];
+    a11[j] = (r >= c) ? A[(16 + r) * 32 + 16 + c] : 0.0;
+  }
+  g_stamp_on = 0;
+  double g00[4], g10[4], g11[4], d0 = 0.0, d1 = 0.0, sink = 0.0;
+  int bad = 0;
+  long long best = 1ll << 60;
+  for (int it = 0; it < reps; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g00[j] = a00[j] + sink * 1e-300;
+      g10[j] = a10[j];
+      g11[j] = a11[j];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const long long t0 = __builtin_readcyclecounter();
+    bad = tile32_potrf_inv(g00, g10, g11, lane, d0, d1);
+    sink = g00[0] + g10[1] + g11[2] + d0 + d1;
+    asm volatile("" ::"v"(sink));
+    const long long t1 = __builtin_readcyclecounter();
+    if (t1 - t0 < best) best = t1 - t0;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * j + q;
+    out[r * 32 + c] = g00[j];
+    out[(16 + r) * 32 + c] = g10[j];
+    out[(16 + r) * 32 + 16 + c] = g11[j];
+    if (r == c) {
+      out[1024 + r] = d0;
+      out[1024 + 16 + r] = d1;
+    }
+  }
+  if (lane == 0) {
+    cyc[0] = best;
+    cyc[1] = bad;
+  }
+}
+
+static int run32(double *dA, double *dout, long long *dcyc) {
+  // SPD 32x32
+  std::vector<double> A(1024), Q(32 * 40);
+  for (double &v : Q) v = rand() / (double)RAND_MAX - 0.5;
+  for (int r = 0; r < 32; ++r)
+    for (int c = 0; c < 32; ++c) {
+      double s = (r == c) ? 0.3 : 0.0;
+      for (int k = 0; k < 40; ++k) s += Q[r * 40 + k] * Q[c * 40 + k];
+      A[r * 32 + c] = s * 1e4;
+    }
+  std::vector<double> L(1024, 0.0);
+  for (int c = 0; c < 32; ++c) {
+    double d = A[c * 32 + c];
+    for (int k = 0; k < c; ++k) d -= L[c * 32 + k] * L[c * 32 + k];
+    L[c * 32 + c] = std::sqrt(d);
+    for (int r2 = c + 1; r2 < 32; ++r2) {
+      double v = A[r2 * 32 + c];
+      for (int k = 0; k < c; ++k) v -= L[r2 * 32 + k] * L[c * 32 + k];
+      L[r2 * 32 + c] = v / L[c * 32 + c];
+    }
+  }
+  // E_tt = inverse transpose of the diagonal 16x16 blocks of L
+  std::vector<double> E(2 * 256, 0.0);
+  for (int t = 0; t < 2; ++t) {
+    std::vector<double> Li(256, 0.0);
+    auto Lt = [&](int i, int j) { return L[(16 * t + i) * 32 + 16 * t + j]; };
+    for (int c = 0; c < 16; ++c) {
+      Li[c * 16 + c] = 1.0 / Lt(c, c);
+      for (int r2 = c + 1; r2 < 16; ++r2) {
+        double v = 0.0;
+        for (int k = c; k < r2; ++k) v -= Lt(r2, k) * Li[k * 16 + c];
+        Li[r2 * 16 + c] = v / Lt(r2, r2);
+      }
+    }
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) E[t * 256 + i * 16 + j] = Li[j * 16 + i];
+  }
+  double *dA32, *dout32;
+  hipMalloc(&dA32, 1024 * 8);
+  hipMalloc(&dout32, (1024 + 32) * 8);
+  hipMemset(dout32, 0, (1024 + 32) * 8);
+  hipMemcpy(dA32, A.data(), 1024 * 8, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_bench32, dim3(1), dim3(64), 0, 0, dA32, dout32, dcyc, 200);
+  if (hipDeviceSynchronize() != hipSuccess) { printf("tile32: kernel failed\n"); return 1; }
+  std::vector<double> out(1024 + 32);
+  long long cyc[2];
+  hipMemcpy(out.data(), dout32, out.size() * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(cyc, dcyc, sizeof(cyc), hipMemcpyDeviceToHost);
+  double eL = 0, nL = 0, eE = 0, nE = 0, eD = 0;
+  for (int r2 = 0; r2 < 32; ++r2)
+    for (int c = 0; c < 32; ++c) {
+      const int tr = r2 / 16, tc = c / 16;
+      if (r2 >= c) {
+        eL = fmax(eL, fabs(out[r2 * 32 + c] - L[r2 * 32 + c]));
+        nL = fmax(nL, fabs(L[r2 * 32 + c]));
+      } else if (tr == tc) {  // strict upper of a diagonal tile: its L^-T
+        const double ref = E[tr * 256 + (r2 % 16) * 16 + (c % 16)];
+        eE = fmax(eE, fabs(out[r2 * 32 + c] - ref));
+        nE = fmax(nE, fabs(ref));
+      }
+    }
+  for (int i = 0; i < 32; ++i) eD = fmax(eD, fabs(out[1024 + i] - E[(i / 16) * 256 + (i % 16) * 17]) / fabs(E[(i / 16) * 256 + (i % 16) * 17]));
+  printf("tile32     %6lld cycles/call  bad %lld  rel err L %.2e  L^-T (diagonal tiles) %.2e  diag %.2e\n", cyc[0], cyc[1],
+         eL / nL, eE / nE, eD);
+  return (eL > 1e-12 * nL || eE > 1e-10 * nE || cyc[1] != 0) ? 1 : 0;
+}
+
 static void host_ref(const std::vector<double> &A, std::vector<double> &L, std::vector<double> &E) {
   // Cholesky L (lower) and E = L^-T (upper)
   L.assign(256, 0.0);
@@ -156,6 +270,7 @@ int main() {
   for (int k = 0; k < 16; ++k) Z[5 * 16 + k] = Z[k * 16 + 5] = 0.0;
   run<0>("current/0", Z, dA, dout, dcyc, true);
   run<1>("new/0", Z, dA, dout, dcyc, true);
+  fail += run32(dA, dout, dcyc);
   printf(fail ? "TILE16 BENCH FAILED\n" : "TILE16 BENCH OK\n");
   return fail;
 }
