@@ -161,7 +161,8 @@ def test_nccl_world1_hook_matches_plain_solve(built):
         dist.destroy_process_group()
 
 
-def test_two_shard_lm_loop_in_one_process(built):
+@pytest.mark.parametrize("dropout", [0.0, 0.15])
+def test_two_shard_lm_loop_in_one_process(dropout, built):
     """The world > 1 LM loop of the library (k_scalars -> exchange 1 -> separate
     k_control; non-direct k_schur_final + k_scatter with the two-stream overlap)
     driven end to end: two shard handles on the one card, each on its own host
@@ -172,7 +173,10 @@ def test_two_shard_lm_loop_in_one_process(built):
     shard's owned points must match the unsharded result."""
     import threading
     import torch
-    sc = scenes.synthetic_ba_scene(30, 2000, 5, True, seed=23, pixel_sigma=0.3)
+    # (dropout: irregular visibility — masked superset groups with padded slots / pairs on
+    #  both shards)
+    sc = scenes.synthetic_ba_scene(30, 2000 if dropout == 0.0 else 5000, 5, True, seed=23, pixel_sigma=0.3,
+                                   dropout=dropout)
     pr = scenes.scaled_problem(sc)
     n_it = 12
     opt = make_options(max_iter=n_it, thr_step=0, thr_cost=0)
@@ -180,6 +184,8 @@ def test_two_shard_lm_loop_in_one_process(built):
     frows, _ = full.solve(opt)
     world = 2
     sh = [make(pr, r, world) for r in range(world)]
+    if dropout > 0:
+        assert all(s_.get_mask_info()["masked_landmarks"] > 0 for s_ in sh)
     bufs = []
     for s_ in sh:
         per = []

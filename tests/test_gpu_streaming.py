@@ -33,6 +33,22 @@ def same_rows(rows, frows, rtol=1e-11):
         assert abs(a.cost - b.cost) <= rtol * abs(b.cost), k
 
 
+def test_streamed_chunks_with_masked_groups(built):
+    """Streaming over a scene with irregular visibility (15 % of the observations dropped:
+    superset groups with padded slots / pairs in every chunk) equals the resident solve."""
+    sc = scenes.synthetic_ba_scene(40, 6000, 5, True, seed=43, pixel_sigma=0.2, dropout=0.15)
+    pr = scenes.scaled_problem(sc)
+    opt = make_options(max_iter=10, thr_step=0, thr_cost=0)
+    full = load(BaProblem(0), pr)
+    assert full.get_mask_info()["masked_landmarks"] > 0
+    frows, _ = full.solve(opt)
+    st = load(BaStream(0, 3, 64 << 20), pr)
+    rows, _ = st.solve(opt)
+    same_rows(rows, frows)
+    assert relerr(st.get_poses(), full.get_poses()) < 1e-9
+    assert relerr(st.get_points(), full.get_points()[0]) < 1e-9
+
+
 @pytest.mark.parametrize("chunks", [1, 2, 5])
 def test_streamed_chunks_match_resident_solve_small(chunks, built):
     """Small stereo scene with pixel noise (rejected steps on the way), a fixed and an
