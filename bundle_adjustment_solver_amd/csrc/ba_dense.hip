@@ -295,8 +295,13 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
   if (tail_cols == 96 && tail_pair)                                                         \
     BA_LAUNCH(K_CHOL_TAIL, (k_chol_tail<6, true>), dim3(1), dim3(256), s, L, ld, npad,      \
               tail_c0, dd.xc, x, dd.col_x, done, bad);                                        \
-  if (flow_back && n_back > 0) {                                                            \
-    BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow, dim3(n_back), dim3(256), s, L, ld, npad,   \
+  if (flow && !flow_back && n_back > 0) {                                                   \
+    BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow<true>, dim3(n_back), dim3(256), s, L, ld,   \
+              npad, dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, \
+              x, dd.col_x, done, dd.flow_flags,                                             \
+              (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad); \
+  } else if (flow_back && n_back > 0) {                                                     \
+    BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow<false>, dim3(n_back), dim3(256), s, L, ld, npad, \
               dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, x,    \
               dd.col_x, done, dd.flow_flags,                                                \
               (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad); \
@@ -372,10 +377,11 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   const bool flow = dd.want_flow && dd.flow_ok && dd.flow_order && dd.n_flow == n_back &&
                     dd.flow_tail_t0 == back_t_end && !fused;
   const int gen_now = ++dd.flow_gen;  // generation number of this solve (flags are never reset)
-  // The dataflow BACKWARD sweep pays for narrow patterns (a hop of ~3 us instead of a
-  // launch per level); with many row tiles per column (dense patterns: DENSE1K, up to
-  // ncb of them) its uncached sc1 gathers of x lose against the per-level launches,
-  // whose gathers hit the L2: 5.0 vs 3.5 ms at DENSE1K.
+  // Two forms of the dataflow BACKWARD sweep.  Narrow patterns: wait for all row tiles,
+  // then gather (their factor tiles prefetched).  Many row tiles per column (dense
+  // patterns: DENSE1K, up to ncb of them): that form puts a 3 MB gather behind the last
+  // hand-off (5.0 ms against 3.5 ms for one launch per level); the ORDERED form consumes
+  // the row tiles one by one as their flags come up.
   const bool flow_back = flow && sc.max_rows <= 12;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)

@@ -1219,6 +1219,28 @@ def test_masked_superset_groups_match_oracle(kind, built, monkeypatch):
         assert abs(a.trial_cost - b.trial_cost) <= 1e-11 * abs(b.trial_cost)
 
 
+def test_dense_pattern_ordered_backward_sweep(built, monkeypatch):
+    """A dense reduced system with more than 12 row tiles per column (170 poses, every
+    landmark seen from 8 random poses: 16 tiles of 64 columns, all coupled) takes the
+    ORDERED dataflow backward sweep (k_chol_back_flow<true>: the row tiles of a column are
+    consumed one by one as their flags come up).  Against the oracle, and against the
+    per-level launches (BA_DENSE_FLOW=0; the summation order of the gather differs:
+    1e-10, not bit-identical)."""
+    sc = scenes.dense_covisibility_scene(170, 5000, 8, seed=51)
+    pr = scenes.scaled_problem(sc)
+    g, o = _compare_solve(pr, iters=6, tol_par=1e-5)
+    assert g.get_dense_info()["fill"] > 0.9 and g.get_dense_info()["levels"] >= 14
+    assert g.get_dropped_pivots() == 0
+    rows, _ = g.solve(make_options(max_iter=4, thr_step=0, thr_cost=0))
+    monkeypatch.setenv("BA_DENSE_FLOW", "0")
+    e = make_gpu(pr)
+    e.solve(make_options(max_iter=6, thr_step=0, thr_cost=0))
+    erows, _ = e.solve(make_options(max_iter=4, thr_step=0, thr_cost=0))
+    for a, b in zip(rows, erows):
+        assert a.iteration_status == b.iteration_status
+        assert abs(a.trial_cost - b.trial_cost) <= 1e-9 * abs(b.trial_cost)
+
+
 def test_update_values_resolves_without_replanning(built):
     """ba_update_values (new values, same structure): after a solve the problem is
     re-seeded with its ORIGINAL values and solved again — the second trajectory and
