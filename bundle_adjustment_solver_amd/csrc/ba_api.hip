@@ -229,6 +229,8 @@ void ba_destroy(ba_handle *h) {
     (void)hipStreamSynchronize(h->side_stream);
     (void)hipStreamDestroy(h->side_stream);
   }
+  for (int k = 0; k < 3; ++k)
+    if (h->ev_look[k]) (void)hipEventDestroy(h->ev_look[k]);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -647,6 +649,13 @@ int ba_finalize(ba_handle *h) {
       return -1;
     dd.col_x = d.col_x;
     dd.read_env();
+    dd.aux_stream = h->side_stream;
+    if (!h->ev_look[0]) {
+      for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&h->ev_look[k], hipEventDisableTiming));
+    }
+    dd.ev_m = h->ev_look[0];
+    dd.ev_x[0] = h->ev_look[1];
+    dd.ev_x[1] = h->ev_look[2];
     {
       std::vector<int> order;
       dd.flow_tail_t0 = ba::dense_flow_order(sc, dd, order);
@@ -1371,6 +1380,13 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   double *dL = nullptr, *dD = nullptr, *dx = nullptr;
   ba::DenseDev dd;
   dd.read_env();
+  dd.aux_stream = h->side_stream;
+  if (!h->ev_look[0]) {
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&h->ev_look[k], hipEventDisableTiming));
+  }
+  dd.ev_m = h->ev_look[0];
+  dd.ev_x[0] = h->ev_look[1];
+  dd.ev_x[1] = h->ev_look[2];
   auto up = [&](int **p, const std::vector<int> &v) -> int {
     HIP_TRY(hipMalloc((void **)p, std::max<size_t>(1, v.size()) * sizeof(int)));
     if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1386,6 +1402,19 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
     HIP_TRY(hipMalloc((void **)&dd.cbuf, (size_t)std::max(1, sc.n_contrib) * nb * nb * sizeof(double)));
   }
   HIP_TRY(hipMalloc((void **)&dd.xc, (size_t)npad * sizeof(double)));
+  {  // the dataflow backward sweep of the LM path (ordered form for dense patterns)
+    std::vector<int> order;
+    dd.flow_tail_t0 = ba::dense_flow_order(sc, dd, order);
+    dd.n_flow = (int)order.size();
+    dd.flow_gen = 0;
+    if (up(&dd.flow_order, order)) return -1;
+    HIP_TRY(hipMalloc((void **)&dd.flow_flags, (size_t)std::max(1, ncb) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&dd.flow_ticket, sizeof(int)));
+    HIP_TRY(hipMemset(dd.flow_flags, 0, (size_t)std::max(1, ncb) * sizeof(int)));
+    HIP_TRY(hipMemset(dd.flow_ticket, 0, sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&dd.bad_pivots, sizeof(int)));
+    HIP_TRY(hipMemset(dd.bad_pivots, 0, sizeof(int)));
+  }
   HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dD, (size_t)ncb * ba::dense_ws_per_block(nb) * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dx, (size_t)npad * sizeof(double)));
@@ -1401,15 +1430,19 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
   (void)hipEventElapsedTime(&t, e0, e1);
   if (ms) *ms = t;
   HIP_TRY(hipMemcpy(x, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  int bad_h = 0;
+  HIP_TRY(hipMemcpy(&bad_h, dd.bad_pivots, sizeof(int), hipMemcpyDeviceToHost));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   for (void *p : {(void *)dL, (void *)dD, (void *)dx, (void *)dd.xc, (void *)dd.row_ptr,
                   (void *)dd.rows, (void *)dd.item_t, (void *)dd.item_I, (void *)dd.tgt_I,
                   (void *)dd.tgt_J, (void *)dd.tgt_src_ptr, (void *)dd.src_t, (void *)dd.col_x,
                   (void *)dd.tgt_desc, (void *)dd.back_desc, (void *)dd.row_desc, (void *)dd.f_desc,
-                  (void *)dd.f_pend, (void *)dd.cbuf})
+                  (void *)dd.f_pend, (void *)dd.cbuf, (void *)dd.flow_order, (void *)dd.flow_flags,
+                  (void *)dd.flow_ticket, (void *)dd.bad_pivots})
     (void)hipFree(p);
   HIP_TRY(hipGetLastError());
+  if (bad_h >= ba::kFlowTimeout) return fail("ba_dense_spd_solve: a dataflow hand-off timed out");
   return 0;
 }
 

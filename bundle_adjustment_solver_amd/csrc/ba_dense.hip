@@ -256,6 +256,43 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
 // target-centric update launch; then one backward launch per level.
 // NS = nb32 or nb64 (the kernels of the schedule's tile order).
 #define BA_DENSE_RUN(NS)                                                                    \
+  if (look) {                                                                               \
+    /* LOOKAHEAD (dense patterns, three-kernel path): the targets of level l that lie in a  \
+       column of level l + 1 are updated first; the factorisation + TRSM of level l + 1 then \
+       run on the auxiliary stream BESIDE the bulk of level l's update */                   \
+    const int nlv = sc.nlev - tail_levels;                                                  \
+    hipStream_t X = dd.aux_stream;                                                          \
+    for (int l = 0; l < nlv; ++l) {                                                         \
+      const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0, nf = sc.tgt_first[l];    \
+      if (l == 0) {                                                                         \
+        const int t0 = sc.lev_ptr[0], nt = sc.lev_ptr[1] - t0;                              \
+        const int it0 = sc.item_ptr[0], ni = sc.item_ptr[1] - it0;                          \
+        BA_LAUNCH(K_CHOL_DIAG, NS::k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag, done, bad); \
+        if (ni > 0)                                                                         \
+          BA_LAUNCH(K_CHOL_TRSM, NS::k_chol_trsm, dim3(ni), dim3(NS::NP * 64), s, L, ld,    \
+                    row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);                     \
+      } else {                                                                              \
+        (void)hipStreamWaitEvent(s, dd.ev_x[l & 1], 0);                                     \
+      }                                                                                     \
+      if (nf > 0)                                                                           \
+        BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(nf), dim3(256), s, L, ld, tg0,     \
+                  dd.tgt_desc, dd.src_t, done);                                             \
+      if (l + 1 < nlv) {                                                                    \
+        const int t1 = sc.lev_ptr[l + 1], nt1 = sc.lev_ptr[l + 2] - t1;                     \
+        const int it1 = sc.item_ptr[l + 1], ni1 = sc.item_ptr[l + 2] - it1;                 \
+        (void)hipEventRecord(dd.ev_m, s);                                                   \
+        (void)hipStreamWaitEvent(X, dd.ev_m, 0);                                            \
+        BA_LAUNCH(K_CHOL_DIAG, NS::k_chol_diag, dim3(nt1), dim3(256), X, L, ld, t1, Ldiag, done, bad); \
+        if (ni1 > 0)                                                                        \
+          BA_LAUNCH(K_CHOL_TRSM, NS::k_chol_trsm, dim3(ni1), dim3(NS::NP * 64), X, L, ld,   \
+                    row_limit, it1, dd.item_t, dd.item_I, Ldiag, done);                     \
+        (void)hipEventRecord(dd.ev_x[(l + 1) & 1], X);                                      \
+      }                                                                                     \
+      if (ng - nf > 0)                                                                      \
+        BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(ng - nf), dim3(256), s, L, ld,     \
+                  tg0 + nf, dd.tgt_desc, dd.src_t, done);                                   \
+    }                                                                                       \
+  } else                                                                                    \
   for (int l = 0; l < sc.nlev - tail_levels; ++l) {                                         \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
     if (fused) {                                                                            \
@@ -383,6 +420,11 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   // hand-off (5.0 ms against 3.5 ms for one launch per level); the ORDERED form consumes
   // the row tiles one by one as their flags come up.
   const bool flow_back = flow && sc.max_rows <= 12;
+  // lookahead over the levels of the three-kernel path (see BA_DENSE_RUN): needs the
+  // auxiliary stream and its events; not under per-kernel timing (serial order) or capture
+  const bool look = split && !fused && dd.want_look && dd.flow_ok && dd.aux_stream && dd.ev_m &&
+                    !(g_ktimer && g_ktimer->on) && sc.nlev - tail_levels >= 3 &&
+                    (int)sc.tgt_first.size() >= sc.nlev;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

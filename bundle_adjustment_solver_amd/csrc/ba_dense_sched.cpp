@@ -115,6 +115,7 @@ void build_one(int ncb, const std::vector<uint8_t> &adj_in, bool natural_order, 
   // work lists per level
   s.item_ptr.assign(1, 0);
   s.tgt_ptr.assign(1, 0);
+  s.tgt_first.clear();
   s.tgt_src_ptr.clear();
   std::vector<std::tuple<int, int, int>> trip;
   for (int l = 0; l < s.nlev; ++l) {
@@ -131,7 +132,16 @@ void build_one(int ncb, const std::vector<uint8_t> &adj_in, bool natural_order, 
     s.item_ptr.push_back((int)s.item_t.size());
     // target-centric: every (I,J) tile touched in this level, with the panels
     // that update it in ascending position order
-    std::sort(trip.begin(), trip.end());
+    // (targets in a column that is eliminated in the NEXT level come first: with
+    //  lookahead — dense patterns — they are updated before the rest, so that the next
+    //  level's factorisation can start beside the bulk of this level's update)
+    auto next_level = [&](int J) { return l + 1 < s.nlev && J >= s.lev_ptr[l + 1] && J < s.lev_ptr[l + 2]; };
+    std::sort(trip.begin(), trip.end(), [&](const std::tuple<int, int, int> &x, const std::tuple<int, int, int> &y) {
+      const int nx = next_level(std::get<1>(x)) ? 0 : 1, ny = next_level(std::get<1>(y)) ? 0 : 1;
+      if (nx != ny) return nx < ny;
+      return x < y;
+    });
+    int n_first = 0;
     for (size_t k = 0; k < trip.size(); ++k) {
       const bool is_new = k == 0 ||
                           std::get<0>(trip[k]) != std::get<0>(trip[k - 1]) ||
@@ -140,9 +150,11 @@ void build_one(int ncb, const std::vector<uint8_t> &adj_in, bool natural_order, 
         s.tgt_I.push_back(std::get<0>(trip[k]));
         s.tgt_J.push_back(std::get<1>(trip[k]));
         s.tgt_src_ptr.push_back((int)s.src_t.size());
+        n_first += next_level(std::get<1>(trip[k])) ? 1 : 0;
       }
       s.src_t.push_back(std::get<2>(trip[k]));
     }
+    s.tgt_first.push_back(n_first);
     s.tgt_ptr.push_back((int)s.tgt_I.size());
   }
   s.tgt_src_ptr.push_back((int)s.src_t.size());

@@ -45,6 +45,7 @@ struct DenseSchedule {
                                    // (ascending positions), rhs block last
   std::vector<int> item_ptr, item_t, item_I;        // TRSM items per level
   std::vector<int> tgt_ptr, tgt_I, tgt_J;           // update targets per level
+  std::vector<int> tgt_first;                       // per level: its first targets that lie in a column of the NEXT level
   std::vector<int> tgt_src_ptr, src_t;              // sources of each target
   // The same lists as fixed 8-int records, so that a workgroup reaches its data
   // after ONE dependent load:

@@ -287,6 +287,11 @@ struct DenseDev {
   bool flow_ok = true;  // false while a hipGraph is captured / replayed (the generation is a kernel argument)
   bool want_flow = true;
   bool force_ticket = false;  // BA_DENSE_TICKET=1: tickets even when the grid is resident (test knob)
+  // lookahead of the three-kernel (dense-pattern) path: an auxiliary stream and its events
+  // (owned by the handle); BA_DENSE_LOOKAHEAD=0 switches it off
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_m = nullptr, ev_x[2] = {nullptr, nullptr};
+  bool want_look = true;
   // BA_DENSE_FUSED / BA_DENSE_SPLIT / BA_DENSE_TAIL as found when the schedule was uploaded
   bool want_fused = false, want_split = false, want_tail = true;
   void read_env() {
@@ -298,6 +303,8 @@ struct DenseDev {
     want_flow = !(fl && fl[0] == '0');
     const char *tk = getenv("BA_DENSE_TICKET");
     force_ticket = tk && tk[0] == '1';
+    const char *la = getenv("BA_DENSE_LOOKAHEAD");
+    want_look = !(la && la[0] == '0');
   }
 };
 struct DenseSchedule;

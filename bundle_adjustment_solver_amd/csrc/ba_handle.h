@@ -48,6 +48,7 @@ struct ba_handle {
   // pose update beside the back-substitution), joined with events
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_look[3] = {nullptr, nullptr, nullptr};  // lookahead of the dense three-kernel path
   bool overlap = true;
   // the side stream holds work of the last enqueued iteration (pose-side
   // linearisation at the trial point, reset of the factor tiles) that the main
