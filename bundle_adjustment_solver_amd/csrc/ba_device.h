@@ -288,10 +288,12 @@ struct DenseDev {
   bool want_flow = true;
   bool force_ticket = false;  // BA_DENSE_TICKET=1: tickets even when the grid is resident (test knob)
   // lookahead of the three-kernel (dense-pattern) path: an auxiliary stream and its events
-  // (owned by the handle); BA_DENSE_LOOKAHEAD=0 switches it off
+  // (owned by the handle).  OPT-IN (BA_DENSE_LOOKAHEAD=1): measured SLOWER on MI355X / ROCm
+  // 7.2 — two cross-stream event hops per level cost more than the factorisation they
+  // hide (n = 5970: 6.5 vs 5.0 ms; DENSE1K 8.1 vs 6.7 ms; C1 0.42 vs 0.31 ms)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_m = nullptr, ev_x[2] = {nullptr, nullptr};
-  bool want_look = true;
+  bool want_look = false;
   // BA_DENSE_FUSED / BA_DENSE_SPLIT / BA_DENSE_TAIL as found when the schedule was uploaded
   bool want_fused = false, want_split = false, want_tail = true;
   void read_env() {
@@ -304,7 +306,7 @@ struct DenseDev {
     const char *tk = getenv("BA_DENSE_TICKET");
     force_ticket = tk && tk[0] == '1';
     const char *la = getenv("BA_DENSE_LOOKAHEAD");
-    want_look = !(la && la[0] == '0');
+    want_look = la && la[0] == '1';
   }
 };
 struct DenseSchedule;
