@@ -215,6 +215,43 @@ int main() {
   EXPECT(max_dp < 1e-6 && max_dx < 1e-6, "final parameters differ from the oracle");
   ba_oracle_destroy(orc);
 
+  // ---------------- re-solve with new VALUES, no re-planning (ReloadParameterValues) ----------------
+  // the caller puts the initial values back into its own objects and has the solver read
+  // them again: the second Solve repeats the first trajectory bit for bit; without the
+  // reload a further Solve continues from the internal state, as the reference does
+  {
+    std::mt19937 gen2(20240601u);
+    std::uniform_real_distribution<float> pe(-0.5f, 0.5f), se(-0.1f, 0.1f);
+    for (int k = 0; k < num_total_poses; ++k) pose_pool[k] = true_poses[k];
+    for (int k = num_fixed_poses; k < num_total_poses; ++k)
+      for (int a = 0; a < 3; ++a) pose_pool[k].translation()(a) += se(gen2);
+    for (size_t i = 0; i < true_points.size(); ++i) {
+      point_pool[(int)i] = true_points[i];
+      for (int a = 0; a < 3; ++a) point_pool[(int)i](a) += pe(gen2);
+    }
+    ba_solver.ReloadParameterValues();
+    Summary again;
+    std::streambuf *keep = std::cerr.rdbuf(captured.rdbuf());
+    ba_solver.Solve(options, &again);
+    std::cerr.rdbuf(keep);
+    const auto &r2 = again.GetOptimizationInfoList();
+    EXPECT(r2.size() == rows.size(), "re-solve: %zu iterations vs %zu", r2.size(), rows.size());
+    bool same = r2.size() == rows.size();
+    for (size_t k = 0; same && k < rows.size(); ++k)
+      same = r2[k].cost == rows[k].cost && r2[k].damping_term == rows[k].damping_term &&
+             r2[k].iteration_status == rows[k].iteration_status;
+    EXPECT(same, "re-solve after ReloadParameterValues must repeat the first trajectory bit for bit");
+    Summary cont;
+    keep = std::cerr.rdbuf(captured.rdbuf());
+    ba_solver.Solve(options, &cont);
+    std::cerr.rdbuf(keep);
+    EXPECT(!cont.GetOptimizationInfoList().empty() &&
+               cont.GetOptimizationInfoList().front().cost < 0.5 * rows.front().cost,
+           "a Solve without reload continues from the internal state");
+    std::printf("re-solve: ReloadParameterValues repeats the first trajectory (%zu iterations), a further Solve continues\n",
+                r2.size());
+  }
+
   // ---------------- refactored API, Gauss-Newton mode (reference test_ba_refactor.cpp:236-299) ----------------
   {
     std::unordered_map<int, Pose> poses2;
