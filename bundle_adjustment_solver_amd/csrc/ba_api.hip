@@ -669,6 +669,15 @@ int ba_finalize(ba_handle *h) {
       HIP_TRY(hipMemset(dd.flow_ticket, 0, sizeof(int)));
       HIP_TRY(hipMemset(dd.fwd_flags, 0, (size_t)std::max(1, ncb) * sizeof(int)));
       HIP_TRY(hipMemset(dd.fwd_ticket, 0, sizeof(int)));
+      std::vector<int> items, pre, need;
+      if (ba::dense_fwd_items(sc, dd, items, pre, need)) {
+        dd.n_fwd_items = (int)items.size() / 2;
+        dd.n_fwd_cnt = (int)need.size();
+        if (h->upload(&dd.fwd_items, items) || h->upload(&dd.upd_pre, pre) || h->upload(&dd.col_need, need) ||
+            h->dalloc(&dd.fwd_cnt, need.size()))
+          return -1;
+        HIP_TRY(hipMemset(dd.fwd_cnt, 0, need.size() * sizeof(int)));
+      }
     }
     HIP_TRY(hipMemset(dd.xc, 0, (size_t)d.npad * sizeof(double)));
     // tiles (re)initialised per iteration: factor pattern + diagonal + rhs row
@@ -1414,6 +1423,19 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
     HIP_TRY(hipMemset(dd.flow_ticket, 0, sizeof(int)));
     HIP_TRY(hipMalloc((void **)&dd.bad_pivots, sizeof(int)));
     HIP_TRY(hipMemset(dd.bad_pivots, 0, sizeof(int)));
+    // the dataflow forward sweep (narrow patterns only: see dense_fwd_items)
+    HIP_TRY(hipMalloc((void **)&dd.fwd_flags, (size_t)std::max(1, ncb) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&dd.fwd_ticket, sizeof(int)));
+    HIP_TRY(hipMemset(dd.fwd_flags, 0, (size_t)std::max(1, ncb) * sizeof(int)));
+    HIP_TRY(hipMemset(dd.fwd_ticket, 0, sizeof(int)));
+    std::vector<int> items, pre, need;
+    if (ba::dense_fwd_items(sc, dd, items, pre, need)) {
+      dd.n_fwd_items = (int)items.size() / 2;
+      dd.n_fwd_cnt = (int)need.size();
+      if (up(&dd.fwd_items, items) || up(&dd.upd_pre, pre) || up(&dd.col_need, need)) return -1;
+      HIP_TRY(hipMalloc((void **)&dd.fwd_cnt, need.size() * sizeof(int)));
+      HIP_TRY(hipMemset(dd.fwd_cnt, 0, need.size() * sizeof(int)));
+    }
   }
   HIP_TRY(hipMalloc((void **)&dL, L.size() * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&dD, (size_t)ncb * ba::dense_ws_per_block(nb) * sizeof(double)));
@@ -1439,7 +1461,9 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
                   (void *)dd.tgt_J, (void *)dd.tgt_src_ptr, (void *)dd.src_t, (void *)dd.col_x,
                   (void *)dd.tgt_desc, (void *)dd.back_desc, (void *)dd.row_desc, (void *)dd.f_desc,
                   (void *)dd.f_pend, (void *)dd.cbuf, (void *)dd.flow_order, (void *)dd.flow_flags,
-                  (void *)dd.flow_ticket, (void *)dd.bad_pivots})
+                  (void *)dd.flow_ticket, (void *)dd.bad_pivots, (void *)dd.fwd_flags,
+                  (void *)dd.fwd_ticket, (void *)dd.fwd_items, (void *)dd.upd_pre, (void *)dd.col_need,
+                  (void *)dd.fwd_cnt})
     (void)hipFree(p);
   HIP_TRY(hipGetLastError());
   if (bad_h >= ba::kFlowTimeout) return fail("ba_dense_spd_solve: a dataflow hand-off timed out");

@@ -292,6 +292,14 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
         BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(ng - nf), dim3(256), s, L, ld,     \
                   tg0 + nf, dd.tgt_desc, dd.src_t, done);                                   \
     }                                                                                       \
+  } else if (fwd_flow) {                                                                    \
+    /* every non-tail level — factorisation + TRSM and updates — in ONE dataflow launch */  \
+    BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_fwd_flow, dim3(dd.n_fwd_items), dim3(256), s, L, \
+              ld, npad, (const int2 *)dd.fwd_items, dd.n_fwd_items, dd.row_desc, dd.rows,   \
+              Ldiag, dd.tgt_desc, dd.src_t, dd.upd_pre, dd.col_need, done, bad,             \
+              dd.fwd_flags, dd.fwd_cnt,                                                     \
+              (dd.n_fwd_items <= kFlowResident && !dd.force_ticket) ? nullptr : dd.fwd_ticket, \
+              gen_now);                                                                     \
   } else                                                                                    \
   for (int l = 0; l < sc.nlev - tail_levels; ++l) {                                         \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
@@ -336,12 +344,14 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow<true>, dim3(n_back), dim3(256), s, L, ld,   \
               npad, dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, \
               x, dd.col_x, done, dd.flow_flags,                                             \
-              (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad); \
+              (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad, \
+              fwd_flow ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
   } else if (flow_back && n_back > 0) {                                                     \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow<false>, dim3(n_back), dim3(256), s, L, ld, npad, \
               dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, x,    \
               dd.col_x, done, dd.flow_flags,                                                \
-              (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad); \
+              (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad, \
+              fwd_flow ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
   } else                                                                                    \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
@@ -378,6 +388,32 @@ int dense_flow_order(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l)
     for (int t = sc.lev_ptr[l]; t < sc.lev_ptr[l + 1]; ++t) order.push_back(t);
   return sc.lev_ptr[sc.nlev - tail_levels];
+}
+
+bool dense_fwd_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &items,
+                     std::vector<int> &pre, std::vector<int> &need) {
+  const bool fused = sc.fused_ok && dd.f_desc && dd.want_fused;
+  const bool split = dd.want_split || !dd.row_desc || sc.max_rows > 4 * (4 / (sc.nb / 16));
+  const int tail_levels = dense_tail_levels(sc, dd, fused, nullptr);
+  const int nlv = sc.nlev - tail_levels;
+  items.clear();
+  pre.assign(std::max<size_t>(1, sc.tgt_J.size()), 0);
+  need.assign((size_t)sc.ncb + 1, 0);
+  if (fused || split || nlv < 2) return false;
+  for (int l = 0; l < nlv; ++l) {
+    for (int t = sc.lev_ptr[l]; t < sc.lev_ptr[l + 1]; ++t) {
+      items.push_back(0);
+      items.push_back(t);
+    }
+    // (targets of one level on one column do not wait for each other: count after the level)
+    for (int tg = sc.tgt_ptr[l]; tg < sc.tgt_ptr[l + 1]; ++tg) {
+      pre[tg] = need[sc.tgt_J[tg]];
+      items.push_back(1);
+      items.push_back(tg);
+    }
+    for (int tg = sc.tgt_ptr[l]; tg < sc.tgt_ptr[l + 1]; ++tg) ++need[sc.tgt_J[tg]];
+  }
+  return true;
 }
 
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
@@ -428,6 +464,10 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   const bool look = split && !fused && dd.want_look && dd.flow_ok && dd.aux_stream && dd.ev_m &&
                     !(g_ktimer && g_ktimer->on) && sc.nlev - tail_levels >= 3 &&
                     (int)sc.tgt_first.size() >= sc.nlev;
+  // the forward sweep of all non-tail levels as one dataflow launch (opt-in, BA_DENSE_FWD_FLOW=1:
+  // see DenseDev::want_fwd_flow); its counters are zeroed again by the backward launch
+  const bool fwd_flow = flow && !split && !look && dd.want_fwd_flow && dd.fwd_flags && dd.fwd_items &&
+                        dd.n_fwd_items > 0 && dd.fwd_cnt && n_back > 0;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

@@ -282,6 +282,18 @@ struct DenseDev {
   // forward sweep, one dataflow launch per level (k_chol_level_flow): one flag per tile
   // ("factorised, row tiles solved"), the ticket counter
   int *fwd_flags = nullptr, *fwd_ticket = nullptr;
+  // forward sweep, ALL non-tail levels as one dataflow launch (k_chol_fwd_flow): the items
+  // {kind, index} in level order, per update target the updates of earlier levels on its
+  // column, per position all updates on its column, the columns' counters of finished updates
+  int *fwd_items = nullptr, *upd_pre = nullptr, *col_need = nullptr, *fwd_cnt = nullptr;
+  int n_fwd_items = 0, n_fwd_cnt = 0;
+  // OPT-IN (BA_DENSE_FWD_FLOW=1; default: one dataflow launch per level).  Measured on MI355X:
+  // the launch itself is shorter than the six it replaces (C4 104 vs 107 us, C2 112 vs 122,
+  // C3 80 vs 87 under per-kernel timing) but the free-running LM iteration is SLOWER (C4
+  // 0.438-0.446 vs 0.433 ms, C2 0.269 vs 0.266, C3 0.258 vs 0.2545): back-to-back launches
+  // on one stream cost less than the polling workgroups of the later levels, which hold
+  // their CU slots from the start of the launch
+  bool want_fwd_flow = false;
   int n_flow = 0, flow_tail_t0 = 0;
   mutable int flow_gen = 0;
   bool flow_ok = true;  // false while a hipGraph is captured / replayed (the generation is a kernel argument)
@@ -303,6 +315,8 @@ struct DenseDev {
     want_tail = !(t && t[0] == '0');
     const char *fl = getenv("BA_DENSE_FLOW");
     want_flow = !(fl && fl[0] == '0');
+    const char *ff = getenv("BA_DENSE_FWD_FLOW");
+    want_fwd_flow = ff && ff[0] == '1';
     const char *tk = getenv("BA_DENSE_TICKET");
     force_ticket = tk && tk[0] == '1';
     const char *la = getenv("BA_DENSE_LOOKAHEAD");
@@ -318,6 +332,11 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const DenseDev &dd, hipStream_t s);
 // positions of the dataflow backward sweep (top level first); returns the tail block's first position
 int dense_flow_order(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &order);
+// work list of the one-launch forward sweep (k_chol_fwd_flow): items = {kind, index} pairs in
+// level order (kind 0: tile position, 1: update target), pre[tg] = updates of earlier levels on
+// the target's column, need[p] = all updates on position p's column; false if the path does not apply
+bool dense_fwd_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &items,
+                     std::vector<int> &pre, std::vector<int> &need);
 void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
                        const int *zt_J, int n_zt, int nb, const int *done_flag,
                        hipStream_t s);

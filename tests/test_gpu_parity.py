@@ -371,13 +371,16 @@ def test_one_stream_iteration_and_dataflow_sweep_equal_their_fallbacks(built):
     the grid is resident, from tickets otherwise: BA_DENSE_TICKET=1 forces tickets);
     BA_FORCE_SIDE=1 (side stream with fork / join) and BA_DENSE_FLOW=0 (separate
     diag_trsm / update launches, one backward launch per level) are the paths every
-    other problem takes: same arithmetic in the same order, so the trajectories must
+    other problem takes; BA_DENSE_FWD_FLOW=1 is the opt-in form that runs ALL levels of
+    the forward sweep as one dataflow launch (k_chol_fwd_flow: per-column counters of
+    finished updates).  Same arithmetic in the same order, so the trajectories must
     agree bit for bit, iteration by iteration."""
     import os
     pr = scenes.scaled_problem(scenes.synthetic_ba_scene(150, 9000, 5, True, seed=33, pixel_sigma=0.3))
     runs = []
     for env in ({}, {"BA_FORCE_SIDE": "1"}, {"BA_DENSE_FLOW": "0"}, {"BA_FORCE_SIDE": "1", "BA_DENSE_FLOW": "0"},
-                {"BA_DENSE_TICKET": "1"}):
+                {"BA_DENSE_TICKET": "1"}, {"BA_DENSE_FWD_FLOW": "1"},
+                {"BA_DENSE_FWD_FLOW": "1", "BA_DENSE_TICKET": "1"}):
         for k, v in env.items():
             os.environ[k] = v
         try:
