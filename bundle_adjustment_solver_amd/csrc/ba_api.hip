@@ -351,12 +351,17 @@ int ba_finalize(ba_handle *h) {
   in.rank = h->rank;
   in.world = h->world;
   const bool times = getenv("BA_PLAN_TIMES") != nullptr;
+  h->up_times = times;
+  h->up_alloc_s = h->up_copy_s = 0;
+  h->up_bytes = h->up_calls = 0;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!times) return;
     (void)hipDeviceSynchronize();
     const auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[finalize] %-26s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t_last).count());
+    fprintf(stderr, "[finalize] %-26s %7.1f ms   (uploads so far: %zu calls, %.1f MB, alloc %.1f ms, copy %.1f ms)\n", what,
+            std::chrono::duration<double, std::milli>(n - t_last).count(), h->up_calls, h->up_bytes / 1e6,
+            h->up_alloc_s * 1e3, h->up_copy_s * 1e3);
     t_last = n;
   };
   std::string err = ba::build_plan(in, h->plan);
@@ -409,11 +414,10 @@ int ba_finalize(ba_handle *h) {
   // slim landmark-major record for the cost kernel (no pair id, 8 bytes)
   d.obs_cp = nullptr;
   const char *wide = getenv("BA_COST_WIDE");  // test knob: keep k_cost on the 16-byte records
-  if (pl.n_cam < 65536 && pl.n_pose < 65536 && pl.n_obs > 0 && !(wide && wide[0] == '1')) {
-    std::vector<int2> cp((size_t)pl.n_obs);
-    for (int64_t k = 0; k < pl.n_obs; ++k)
-      cp[k] = make_int2(pl.obs_idx[4 * k + 0] | (pl.obs_idx[4 * k + 1] << 16), pl.obs_idx[4 * k + 2]);
-    if (h->upload(&d.obs_cp, cp)) return -1;
+  if (!pl.obs_cp.empty() && pl.n_obs > 0 && !(wide && wide[0] == '1')) {  // (filled by the planner's threaded pass)
+    static_assert(sizeof(int2) == 8, "layout");
+    if (h->dalloc(&d.obs_cp, (size_t)pl.n_obs)) return -1;
+    HIP_TRY(hipMemcpy(d.obs_cp, pl.obs_cp.data(), (size_t)pl.n_obs * 8, hipMemcpyHostToDevice));
   }
   if (h->dalloc(&d.pobs_idx, (size_t)pl.n_pobs)) return -1;
   if (h->dalloc(&d.pobs_uv, (size_t)pl.n_pobs)) return -1;
@@ -489,13 +493,18 @@ int ba_finalize(ba_handle *h) {
   if (h->dalloc(&d.spart2, (size_t)d.n_slot * ba::kSlotStride)) return -1;
   h->kind(1);
   {
-    static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 64,
+    static_assert(sizeof(ba::Plan::GrpDesc) == sizeof(ba::DevProblem::GrpDesc) && sizeof(ba::Plan::GrpDesc) == 128,
                   "group descriptor layout");
     static_assert(sizeof(ba::Plan::LinDesc) == sizeof(ba::DevProblem::LinDesc) && sizeof(ba::Plan::LinDesc) == 48,
                   "group linearisation descriptor layout");
     d.n_grp32 = (int)pl.grp32.size();
     d.n_grp64 = (int)pl.grp64.size();
-    if (h->dalloc(&d.grp32, pl.grp32.size()) || h->dalloc(&d.grp64, pl.grp64.size())) return -1;
+    d.n_grp128 = (int)pl.grp128.size();
+    if (h->dalloc(&d.grp32, pl.grp32.size()) || h->dalloc(&d.grp64, pl.grp64.size()) ||
+        h->dalloc(&d.grp128, pl.grp128.size()))
+      return -1;
+    if (d.n_grp128)
+      HIP_TRY(hipMemcpy(d.grp128, pl.grp128.data(), pl.grp128.size() * sizeof(ba::Plan::GrpDesc), hipMemcpyHostToDevice));
     if (d.n_grp32)
       HIP_TRY(hipMemcpy(d.grp32, pl.grp32.data(), pl.grp32.size() * sizeof(ba::Plan::GrpDesc), hipMemcpyHostToDevice));
     if (d.n_grp64)
@@ -1288,19 +1297,19 @@ int ba_get_schur_info(ba_handle *h, int64_t out8[8]) {
   if (!h || !h->finalized || !out8) return fail("ba_get_schur_info: bad argument");
   const ba::Plan &pl = h->plan;
   int64_t pairs = 0, triples = 0, mfma = 0;
-  for (const auto *list : {&pl.grp32, &pl.grp64})
+  for (const auto *list : {&pl.grp32, &pl.grp64, &pl.grp128})
     for (const auto &g : *list) {
       pairs += (int64_t)g.nl * g.d;
       triples += (int64_t)g.nl * g.d * (g.d + 1) / 2;
       // v_mfma_f64_16x16x4 instructions of k_schur_grp: chunks of nlw landmarks,
       // ceil(3 nlc / 4) k steps each, NT (NT + 1) / 2 tiles per step
-      const int nt = list == &pl.grp32 ? 2 : 4, krw = nt == 2 ? 36 : 20;
+      const int nt = list == &pl.grp32 ? 2 : (list == &pl.grp64 ? 4 : 8), krw = nt == 2 ? 36 : (nt == 4 ? 20 : 8);
       const int nlw = std::min(64 / g.d, krw / 3);
       for (int c0 = 0; c0 < g.nl; c0 += nlw)
         mfma += (int64_t)((3 * std::min(nlw, g.nl - c0) + 3) / 4) * (nt * (nt + 1) / 2);
     }
   out8[0] = (int64_t)pl.grp32.size();
-  out8[1] = (int64_t)pl.grp64.size();
+  out8[1] = (int64_t)(pl.grp64.size() + pl.grp128.size());  // (64- and 128-wide images)
   out8[2] = pl.M_grp;
   out8[3] = (int64_t)pl.sup_desc.size();
   out8[4] = pairs;

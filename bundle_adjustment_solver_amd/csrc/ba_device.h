@@ -97,7 +97,8 @@ struct DevProblem {
   struct GrpDesc {
     int64_t p0;
     int32_t l0, nl, d, s0;
-    int32_t pose[10];
+    int32_t pose[20];
+    int32_t pad_[6];
   };
   struct LinDesc {  // one k_lin_grp workgroup: layout-identical to Plan::LinDesc
     int64_t p0, o0;
@@ -109,8 +110,8 @@ struct DevProblem {
   LinDesc *lin_desc;
   int n_lin_desc;
   int n_lin_plain;  // pieces [0, n_lin_plain): exact groups; behind them: masked (superset) groups
-  GrpDesc *grp32, *grp64;  // pose sets of <= 5 / 6..10 poses
-  int n_grp32, n_grp64;
+  GrpDesc *grp32, *grp64, *grp128;  // pose sets of <= 5 / 6..10 / 11..20 poses
+  int n_grp32, n_grp64, n_grp128;
   // k_lin_grp (groups linearised landmark and pose side in one pass): per pattern
   // slot {pose, camera | jj << 16 | optimisable << 29 | last writer << 30}
   int2 *grp_pat;

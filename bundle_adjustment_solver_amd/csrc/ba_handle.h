@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -140,14 +141,27 @@ struct ba_handle {
     allocs.push_back((void *)*p);
     return 0;
   }
+  // BA_PLAN_TIMES: bytes / seconds spent in upload() (allocation and copy apart)
+  bool up_times = false;
+  double up_alloc_s = 0, up_copy_s = 0;
+  size_t up_bytes = 0, up_calls = 0;
   template <class T, class A>
   int upload(T **p, const std::vector<T, A> &v) {
+    const auto t0 = up_times ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (dalloc(p, v.size())) return -1;
+    const auto t1 = up_times ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (!v.empty()) {
       hipError_t e = hipMemcpy(*p, v.data(), v.size() * sizeof(T),
                                hipMemcpyHostToDevice);
       if (e != hipSuccess)
         return ::ba::fail(std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+    }
+    if (up_times) {
+      const auto t2 = std::chrono::steady_clock::now();
+      up_alloc_s += std::chrono::duration<double>(t1 - t0).count();
+      up_copy_s += std::chrono::duration<double>(t2 - t1).count();
+      up_bytes += v.size() * sizeof(T);
+      ++up_calls;
     }
     return 0;
   }

@@ -716,7 +716,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, in
   __shared__ __attribute__((aligned(16))) double red[4 * kLgArea];
   __shared__ double cams_s[kCamLds * 16];
   __shared__ double smc[4];
-  __shared__ int slot_b[10], slot_e[10];  // pattern slots of pose jj of the group (<= kGrpMaxPoses poses)
+  __shared__ int slot_b[kGrpMaxPoses], slot_e[kGrpMaxPoses];  // pattern slots of pose jj of the group
   const int bid = piece0 + blockIdx.x;
   const DevProblem::LinDesc *gp = d.lin_desc + bid;
   const int64_t p0 = gp->p0, o0 = gp->o0;
@@ -1667,6 +1667,162 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
       __syncthreads();
       ++tile;
     }
+}
+
+// Pose sets of 11..20 poses (6 d + 1 <= 121 columns: a 128-wide image, 36 upper 16x16
+// tiles).  144 accumulator registers per wave do not fit beside the staging arithmetic,
+// so here the four waves split the TILES, not the chunks: a stage = 4 x nlw landmarks
+// (nlw = min(64 / d, 2) per wave, one lane per (landmark, pose) pair) staged by all waves
+// into ONE shared image of <= 24 k rows; after a workgroup barrier wave w multiplies
+// the image into ITS nine tiles — tile rows w and 7 - w of the upper triangle — so
+// every tile has one owner, the operands of a k step are 2 + 9 LDS reads per lane for 9
+// MFMAs, and there is no final sum over waves: a wave scatters its tiles to the group's
+// slots itself.  Same arithmetic as k_schur_grp per entry; the k order is the landmark
+// order (deterministic).
+__global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, const DevProblem::GrpDesc *grps) {
+  constexpr int TW = 128;
+  constexpr int LPW = 2;            // landmarks a wave stages per stage
+  constexpr int KRW = 4 * LPW * 3;  // k rows of a stage
+  constexpr int RS = 2 * TW + 6;    // doubles per pair of k rows (+ padding: see k_schur_grp)
+  constexpr int IMG = (KRW / 2) * RS;
+  __shared__ __attribute__((aligned(16))) double VA[IMG];
+  __shared__ __attribute__((aligned(16))) double WB[IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const DevProblem::GrpDesc *gp = grps + blockIdx.x;
+  const int64_t gp0 = gp->p0;
+  const int gl0 = gp->l0, gnl = gp->nl, dd = gp->d, gs0 = gp->s0;
+  const int done = d.ctrl->done;
+  const int lb = d.ctrl->lcur;
+  if (done) return;
+  const double *__restrict__ Wg = d.W[lb];
+  const double *__restrict__ bg = d.b[lb];
+  const double *__restrict__ Cug = d.Cu[lb];
+  const double lp1 = 1.0 + d.ctrl->lambda;
+  const int nlw = min(64 / dd, LPW);
+  const int il = lane / dd, jj = lane - il * dd;
+  const int li = wv * nlw + il;  // this lane's landmark inside a stage
+  const int per_stage = 4 * nlw;
+  const int nst = (gnl + per_stage - 1) / per_stage;
+  for (int e = tid; e < IMG; e += kBlock) {  // rows a full stage never writes stay zero
+    VA[e] = 0.0;
+    WB[e] = 0.0;
+  }
+  double2 rw[2][6], rc[2][3];
+  double rb[2][3];
+#define GW_PREFETCH(B, st_)                                                         \
+  {                                                                                 \
+    const int c0_ = (st_) * per_stage;                                              \
+    const bool on_ = il < nlw && c0_ + li < gnl;                                     \
+    const double2 *wp_ = (const double2 *)(Wg + (size_t)(gp0 + (int64_t)(c0_ + wv * nlw) * dd + (on_ ? lane : 0)) * kWStride); \
+    const int lm_ = gl0 + (on_ ? c0_ + li : 0);                                     \
+    const double2 *cp_ = (const double2 *)(Cug + (size_t)lm_ * 6);                  \
+    if (!on_) wp_ = (const double2 *)(Wg + (size_t)gp0 * kWStride);                 \
+    _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) rw[B][k_] = wp_[k_];           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) rc[B][k_] = cp_[k_];           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) rb[B][k_] = bg[(size_t)lm_ * 3 + k_]; \
+  }
+  v4f64 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  // this wave's tiles: t < n_first: (ti, tj) = (wv, wv + t); else (7 - wv, 7 - wv + t - n_first)
+  const int n_first = 8 - wv;
+  GW_PREFETCH(0, 0)
+  if (nst > 1) GW_PREFETCH(1, 1)
+#define GW_IDX(k_, col_) (((k_) >> 1) * RS + (col_) * 2 + ((k_) & 1))
+#define GW_STAGE(B)                                                                 \
+  {                                                                                 \
+    const int c0 = st * per_stage;                                                  \
+    const int nlc = min(per_stage, gnl - c0);                                       \
+    if (il < nlw && li < nlc) {                                                     \
+      const double k9[9] = {rw[B][0].x, rw[B][0].y, rw[B][1].x, rw[B][1].y, rw[B][2].x, \
+                            rw[B][2].y, rw[B][3].x, rw[B][3].y, rw[B][4].x};        \
+      const double x0 = rw[B][4].y, x1 = rw[B][5].x, x2 = rw[B][5].y;               \
+      const double cd_[6] = {rc[B][0].x * lp1, rc[B][0].y, rc[B][1].x, rc[B][1].y * lp1, rc[B][2].x, rc[B][2].y * lp1}; \
+      double c6[6];                                                                 \
+      spd3_inverse(cd_, c6);                                                        \
+      double w[18];                                                                 \
+      _Pragma("unroll") for (int e = 0; e < 9; ++e) w[e] = k9[e];                   \
+      _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
+        w[9 + c] = x1 * k9[6 + c] - x2 * k9[3 + c];                                 \
+        w[12 + c] = x2 * k9[c] - x0 * k9[6 + c];                                    \
+        w[15 + c] = x0 * k9[3 + c] - x1 * k9[c];                                    \
+      }                                                                             \
+      const int kb = 3 * li, cb = 6 * jj;                                           \
+      const int i0 = GW_IDX(kb, cb), i1 = GW_IDX(kb + 1, cb), i2 = GW_IDX(kb + 2, cb); \
+      _Pragma("unroll") for (int r = 0; r < 6; ++r) {                               \
+        const double w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];           \
+        VA[i0 + 2 * r] = w0 * c6[0] + w1 * c6[1] + w2 * c6[2];                      \
+        VA[i1 + 2 * r] = w0 * c6[1] + w1 * c6[3] + w2 * c6[4];                      \
+        VA[i2 + 2 * r] = w0 * c6[2] + w1 * c6[4] + w2 * c6[5];                      \
+        WB[i0 + 2 * r] = w0;                                                        \
+        WB[i1 + 2 * r] = w1;                                                        \
+        WB[i2 + 2 * r] = w2;                                                        \
+      }                                                                             \
+      if (jj == 0) {                                                                \
+        WB[GW_IDX(kb, 6 * dd)] = rb[B][0];                                          \
+        WB[GW_IDX(kb + 1, 6 * dd)] = rb[B][1];                                      \
+        WB[GW_IDX(kb + 2, 6 * dd)] = rb[B][2];                                      \
+      }                                                                             \
+    }                                                                               \
+    const int nks = (3 * nlc + 3) >> 2;                                             \
+    if (nlc < per_stage) { /* partial last stage: stale rows up to the next multiple of four */ \
+      for (int e = tid; e < (4 * nks - 3 * nlc) * TW; e += kBlock) {                \
+        const int k_ = 3 * nlc + e / TW, c_ = e - (e / TW) * TW;                    \
+        VA[GW_IDX(k_, c_)] = 0.0;                                                   \
+        WB[GW_IDX(k_, c_)] = 0.0;                                                   \
+      }                                                                             \
+    }                                                                               \
+    if (st + 2 < nst) GW_PREFETCH(B, st + 2)                                        \
+    __syncthreads();                                                                \
+    {                                                                               \
+      const double *ap = VA + (lk >> 1) * RS + lr * 2 + (lk & 1);                   \
+      const double *bp = WB + (lk >> 1) * RS + lr * 2 + (lk & 1);                   \
+      for (int ks = 0; ks < nks; ++ks) {                                            \
+        const double a0 = ap[ks * 2 * RS + 32 * wv], a1 = ap[ks * 2 * RS + 32 * (7 - wv)]; \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) {                             \
+          const bool first = t < n_first;                                           \
+          const int tj = first ? wv + t : 7 - wv + (t - n_first);                   \
+          const double bv = bp[ks * 2 * RS + 32 * tj];                              \
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(first ? a0 : a1, bv, acc[t], 0, 0, 0); \
+        }                                                                           \
+      }                                                                             \
+    }                                                                               \
+    __syncthreads();                                                                \
+    ++st;                                                                           \
+  }
+  __syncthreads();
+  for (int st = 0; st < nst;) {
+    GW_STAGE(0)
+    if (st >= nst) break;
+    GW_STAGE(1)
+  }
+#undef GW_STAGE
+#undef GW_IDX
+#undef GW_PREFETCH
+  // every tile has one owner: the wave scatters its nine tiles to the group's slots
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const bool first = t < n_first;
+    const int ti = first ? wv : 7 - wv;
+    const int tj = first ? wv + t : 7 - wv + (t - n_first);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const double v = acc[t][g];
+      const int row = 16 * ti + lk + 4 * g;  // V side: 6 pj + r
+      const int col = 16 * tj + lr;          // W side: 6 pk + c, or the b column
+      const int pj = row / 6, r = row - 6 * pj;
+      if (pj < dd) {
+        const int sj = gs0 + pj * dd - (pj * (pj - 1)) / 2;  // slot of (pj, pj)
+        if (col == 6 * dd) {
+          d.spart2[(size_t)sj * kSlotStride + 36 + r] = v;
+        } else if (col < 6 * dd) {
+          const int pk = col / 6, c = col - 6 * pk;
+          if (pk >= pj) d.spart2[(size_t)(sj + (pk - pj)) * kSlotStride + r * 6 + c] = v;
+        }
+      }
+    }
+  }
 }
 
 // Same sums for landmarks seen by more than kSchurPairs poses: one wave per
@@ -2693,6 +2849,8 @@ void launch_schur_accumulate(const DevProblem &d, hipStream_t s) {
     BA_LAUNCH(K_SCHUR_GRP, k_schur_grp<2>, dim3(d.n_grp32), dim3(kBlock), s, d, d.grp32);
   if (d.n_grp64 > 0)
     BA_LAUNCH(K_SCHUR_GRP, k_schur_grp<4>, dim3(d.n_grp64), dim3(kBlock), s, d, d.grp64);
+  if (d.n_grp128 > 0)
+    BA_LAUNCH(K_SCHUR_GRP, k_schur_grp_wide, dim3(d.n_grp128), dim3(kBlock), s, d, d.grp128);
   if (d.n_sup > 0)
     BA_LAUNCH(K_SCHUR_LDS, k_schur_lds, dim3(d.n_sup), dim3(kBlock), s, d);
   if (d.n_tchunk > 0)

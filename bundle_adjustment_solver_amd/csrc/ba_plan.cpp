@@ -4,6 +4,7 @@
 #include "ba_dense_sched.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <limits>
 #include <cstdio>
@@ -11,7 +12,18 @@
 #include <numeric>
 #include <thread>
 
+#include <sys/mman.h>
+
 namespace ba {
+
+void *plan_big_alloc(size_t bytes) {
+  void *p = nullptr;
+  const size_t sz = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  if (posix_memalign(&p, (size_t)2 << 20, sz) != 0 || !p) throw std::bad_alloc();
+  (void)madvise(p, sz, MADV_HUGEPAGE);  // advisory: plain pages when THP is off
+  return p;
+}
+void plan_big_free(void *p, size_t) { free(p); }
 
 namespace {
 
@@ -81,12 +93,16 @@ void locality_order(const PlanInput &in,
                     std::vector<int64_t> &obs_count) {
   std::vector<int32_t> first_pose(in.n_pt, in.n_pose);
   obs_count.assign(in.n_pt, 0);
-  for (int64_t k = 0; k < in.n_obs; ++k) {
-    const int q = in.obs_pt[k];
-    const int j = pose_int_of_user[in.obs_pose[k]];
-    if (j < first_pose[q]) first_pose[q] = j;
-    obs_count[q]++;
-  }
+  // (threaded by point range: every thread scans the whole list and keeps its own points)
+  parallel_for(in.n_pt, [&](int64_t q0, int64_t q1) {
+    for (int64_t k = 0; k < in.n_obs; ++k) {
+      const int64_t q = in.obs_pt[k];
+      if (q < q0 || q >= q1) continue;
+      const int j = pose_int_of_user[in.obs_pose[k]];
+      if (j < first_pose[q]) first_pose[q] = j;
+      obs_count[q]++;
+    }
+  });
   // counting sort by first_pose keeps input index order inside a bucket
   std::vector<int64_t> bucket(in.n_pose + 2, 0);
   for (int q = 0; q < in.n_pt; ++q) bucket[first_pose[q] + 1]++;
@@ -220,15 +236,27 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   if (in.n_pt <= 0) return "no points";
   if (in.world < 1 || in.rank < 0 || in.rank >= in.world)
     return "bad rank/world";
-  for (int64_t k = 0; k < in.n_obs; ++k) {
-    if (in.obs_cam[k] < 0 || in.obs_cam[k] >= in.n_cam)
-      return "observation with invalid camera index";
-    if (in.obs_pose[k] < 0 || in.obs_pose[k] >= in.n_pose)
-      return "observation with invalid pose index";
-    if (in.obs_pt[k] < 0 || in.obs_pt[k] >= in.n_pt)
-      return "observation with invalid point index";
-  }
   PhaseClock clk;
+  {
+    // first offending observation (the smallest index, whatever the thread count)
+    std::vector<int64_t> bad((size_t)plan_threads() + 1, INT64_MAX);
+    std::atomic<int> slot{0};
+    parallel_for(in.n_obs, [&](int64_t k0, int64_t k1) {
+      const int me = slot.fetch_add(1);
+      for (int64_t k = k0; k < k1; ++k)
+        if (in.obs_cam[k] < 0 || in.obs_cam[k] >= in.n_cam || in.obs_pose[k] < 0 || in.obs_pose[k] >= in.n_pose ||
+            in.obs_pt[k] < 0 || in.obs_pt[k] >= in.n_pt) {
+          bad[me] = k;
+          break;
+        }
+    });
+    const int64_t k = *std::min_element(bad.begin(), bad.end());
+    if (k != INT64_MAX) {
+      if (in.obs_cam[k] < 0 || in.obs_cam[k] >= in.n_cam) return "observation with invalid camera index";
+      if (in.obs_pose[k] < 0 || in.obs_pose[k] >= in.n_pose) return "observation with invalid pose index";
+      return "observation with invalid point index";
+    }
+  }
   pl = Plan();
   pl.n_cam = in.n_cam;
   pl.n_pose = in.n_pose;
@@ -272,9 +300,16 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   // ---- observations of the OWNED points as a CSR over user point ids, every list in
   // (pose, insertion) order: built once, used by the covisibility grouping below and,
   // landmark by landmark in the final order, by the landmark-major list ----
+  // (counting sort by point id, threaded by POINT RANGE: every thread scans the whole
+  //  observation list — a sequential read — and files the observations of its own points,
+  //  in input order: the result does not depend on the thread count)
   std::vector<int64_t> uo_ptr((size_t)in.n_pt + 1, 0);
-  for (int64_t k = 0; k < in.n_obs; ++k)
-    if (pl.owner[in.obs_pt[k]] == in.rank) uo_ptr[in.obs_pt[k] + 1]++;
+  parallel_for(in.n_pt, [&](int64_t q0, int64_t q1) {
+    for (int64_t k = 0; k < in.n_obs; ++k) {
+      const int64_t q = in.obs_pt[k];
+      if (q >= q0 && q < q1 && pl.owner[q] == in.rank) uo_ptr[q + 1]++;
+    }
+  });
   for (int q = 0; q < in.n_pt; ++q) uo_ptr[q + 1] += uo_ptr[q];
   // (packed records: every later pass reads a landmark's observations as ONE contiguous
   //  run instead of gathering four input arrays at random positions)
@@ -284,16 +319,19 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   };
   pvec<ObsRecP> uo_rec((size_t)uo_ptr[in.n_pt]);
   {
-    std::vector<int64_t> cur(uo_ptr.begin(), uo_ptr.end() - 1);
-    for (int64_t k = 0; k < in.n_obs; ++k) {
-      const int q = in.obs_pt[k];
-      if (pl.owner[q] != in.rank) continue;
-      ObsRecP &r = uo_rec[cur[q]++];
-      r.pose = pl.pose_int_of_user[in.obs_pose[k]];
-      r.cam = in.obs_cam[k];
-      r.u = in.obs_uv ? in.obs_uv[2 * k + 0] : 0.0;
-      r.v = in.obs_uv ? in.obs_uv[2 * k + 1] : 0.0;
-    }
+    pvec<int64_t> cur((size_t)in.n_pt);
+    parallel_for(in.n_pt, [&](int64_t q0, int64_t q1) {
+      for (int64_t q = q0; q < q1; ++q) cur[q] = uo_ptr[q];
+      for (int64_t k = 0; k < in.n_obs; ++k) {
+        const int64_t q = in.obs_pt[k];
+        if (q < q0 || q >= q1 || pl.owner[q] != in.rank) continue;
+        ObsRecP &r = uo_rec[cur[q]++];
+        r.pose = pl.pose_int_of_user[in.obs_pose[k]];
+        r.cam = in.obs_cam[k];
+        r.u = in.obs_uv ? in.obs_uv[2 * k + 0] : 0.0;
+        r.v = in.obs_uv ? in.obs_uv[2 * k + 1] : 0.0;
+      }
+    });
   }
   parallel_for(in.n_pt, [&](int64_t q0, int64_t q1) {
     for (int64_t q = q0; q < q1; ++q) {
@@ -325,7 +363,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       const int q = pl.pt_user_of_int[i];
       kp[i + 1] = kp[i] + (uo_ptr[q + 1] - uo_ptr[q]);
     }
-    std::vector<uint64_t> pat((size_t)kp[M0]);  // (pose << 32) | camera, per point in (pose, insertion) order
+    pvec<uint64_t> pat((size_t)kp[M0]);  // (pose << 32) | camera, per point in (pose, insertion) order
     parallel_for(M0, [&](int64_t i0, int64_t i1) {
       for (int64_t i = i0; i < i1; ++i) {
         const int q = pl.pt_user_of_int[i];
@@ -334,6 +372,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           pat[w++] = ((uint64_t)(uint32_t)uo_rec[t].pose << 32) | (uint32_t)uo_rec[t].cam;
       }
     });
+    clk.lap("  groups: patterns");
     auto deg = [&](int i) { return (int)(kp[i + 1] - kp[i]); };
     auto dopt = [&](int i) {  // distinct optimisable poses
       int n = 0;
@@ -363,6 +402,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       //  back-substituted: groups of them keep those kernels' chunk launches empty)
       if (dop[i] <= kGrpMaxPoses && deg(i) >= 1 && deg(i) <= kGrpMaxObs) cand.push_back(i);
     }
+    clk.lap("  groups: candidates");
     // stable sort by pattern (stable: locality order inside a group).  The candidates
     // arrive in locality order, i.e. already grouped by their first observing pose = the
     // first pattern word's pose: every run of equal first pose is sorted on its own, the
@@ -381,11 +421,13 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         std::stable_sort(cand.begin(), cand.end(), less_sig);
       } else {
         parallel_for((int64_t)run0.size() - 1, [&](int64_t r0, int64_t r1) {
-          for (int64_t r = r0; r < r1; ++r)
-            std::stable_sort(cand.begin() + run0[r], cand.begin() + run0[r + 1], less_sig);
+          for (int64_t r = r0; r < r1; ++r)  // (regular scenes: one pattern per run, nothing to sort)
+            if (!std::is_sorted(cand.begin() + run0[r], cand.begin() + run0[r + 1], less_sig))
+              std::stable_sort(cand.begin() + run0[r], cand.begin() + run0[r + 1], less_sig);
         });
       }
     }
+    clk.lap("  groups: pattern sort");
     // ---- groups.  A run of candidates with the IDENTICAL pattern is an exact group (as
     // before).  SUPERSET groups (round 3) take what real visibility leaves of that —
     // occlusion, image borders, track loss make the patterns of one pose window differ
@@ -469,11 +511,19 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       exact_runs(0, cand.size());
     } else {
       // buckets of equal (first pose, last pose); inside a bucket the pattern order stays
-      std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) {
-        const int32_t fx = first_pose(x), fy = first_pose(y);
-        if (fx != fy) return fx < fy;
-        return last_pose(x) < last_pose(y);
-      });
+      // (stable, by two counting passes — last pose, then first pose)
+      {
+        std::vector<int32_t> tmp(cand.size());
+        auto pass = [&](const std::vector<int32_t> &key, const std::vector<int32_t> &src, std::vector<int32_t> &dst) {
+          std::vector<int64_t> at((size_t)in.n_pose + 1, 0);
+          for (int32_t i : src) at[(size_t)key[i] + 1]++;
+          for (int b = 0; b < in.n_pose; ++b) at[b + 1] += at[b];
+          for (int32_t i : src) dst[at[key[i]]++] = i;
+        };
+        pass(span_hi, cand, tmp);
+        pass(span_lo, tmp, cand);
+      }
+      clk.lap("  groups: span sort");
       size_t a = 0;
       std::vector<uint64_t> uni;
       while (a < cand.size()) {
@@ -520,6 +570,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         }
         a = b;
       }
+      clk.lap("  groups: buckets");
       // leftovers join a group whose union contains their pattern
       std::vector<std::vector<int32_t>> by_first(in.n_pose + 1);
       for (size_t gidx = 0; gidx < groups.size(); ++gidx)
@@ -541,6 +592,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           }
       }
     }
+    clk.lap("  groups: leftovers");
     std::vector<int32_t> neworder;
     neworder.reserve(M0);
     pl.grp_upat.clear();
@@ -640,6 +692,9 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     if (pptr[n_own] >= (int64_t)INT32_MAX) return "too many pairs for int32 pair ids";
     pl.obs_idx.resize((size_t)pl.n_obs * 4);
     pl.obs_uv.resize((size_t)pl.n_obs * 2);
+    const bool slim = pl.n_cam < 65536 && pl.n_pose < 65536;
+    pl.obs_cp.clear();
+    if (slim) pl.obs_cp.resize((size_t)pl.n_obs * 2);
     pl.lm_obs_ptr.assign(M + 1, 0);
     pl.lm_pair_ptr.assign(M + 1, 0);
     pl.pair_pose.resize((size_t)pptr[n_own]);
@@ -661,6 +716,10 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
             pl.obs_idx[4 * s + 1] = ji;
             pl.obs_idx[4 * s + 2] = (int32_t)pi;
             pl.obs_idx[4 * s + 3] = -1;
+            if (slim) {
+              pl.obs_cp[2 * s + 0] = cam | (ji << 16);
+              pl.obs_cp[2 * s + 1] = (int32_t)pi;
+            }
             pl.obs_uv[2 * s + 0] = have ? uo_rec[t].u : std::numeric_limits<double>::quiet_NaN();
             pl.obs_uv[2 * s + 1] = have ? uo_rec[t].v : std::numeric_limits<double>::quiet_NaN();
             if (ji < N) {
@@ -690,6 +749,10 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           pl.obs_idx[4 * s + 1] = ji;
           pl.obs_idx[4 * s + 2] = (int32_t)pi;
           pl.obs_idx[4 * s + 3] = -1;
+          if (slim) {
+            pl.obs_cp[2 * s + 0] = r.cam | (ji << 16);
+            pl.obs_cp[2 * s + 1] = (int32_t)pi;
+          }
           pl.obs_uv[2 * s + 0] = r.u;
           pl.obs_uv[2 * s + 1] = r.v;
           if (pi < M && ji < N) {
@@ -722,14 +785,29 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
   pl.n_obs_opt = pl.lm_obs_ptr[M];
   pl.P = (int64_t)pl.pair_pose.size();
 
+  // (the per-point lists are not needed any more: their 140 MB go back to the system on a
+  //  side thread while the remaining phases run)
+  struct Reaper {
+    std::thread t;
+    ~Reaper() {
+      if (t.joinable()) t.join();
+    }
+  } reaper;
+  reaper.t = std::thread([a = std::move(uo_rec), b = std::move(uo_ptr)]() mutable {
+    a = decltype(a)();
+    b = decltype(b)();
+  });
   clk.lap("landmark-major list");
   // ---- pose-major observation list (optimisable poses) ----
   {
     std::vector<int64_t> psel;
-    psel.reserve(pl.n_obs);
+    // (the landmark-major list is in landmark order: the grouped landmarks' observations,
+    //  which never enter, are its first lm_obs_ptr[M_grp] entries)
+    const int64_t s_first = pl.lin_groups ? pl.lm_obs_ptr[pl.M_grp] : 0;
+    psel.reserve((size_t)(pl.n_obs - s_first));
     // (observations of landmarks in covisibility groups are linearised, pose side
     //  included, by k_lin_grp: they do not enter the pose-major list)
-    for (int64_t s = 0; s < pl.n_obs; ++s)
+    for (int64_t s = s_first; s < pl.n_obs; ++s)
       if (pl.obs_idx[4 * s + 1] < N && !(pl.lin_groups && pl.obs_idx[4 * s + 2] < pl.M_grp)) psel.push_back(s);
     // stable counting sort by pose keeps (point, insertion) order inside
     pl.pose_obs_ptr.assign(N + 1, 0);
@@ -850,7 +928,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     for (int i = 0; i < M; ++i) {
       const int64_t d = pl.lm_pair_ptr[i + 1] - pl.lm_pair_ptr[i];
       Tall += d * (d + 1) / 2;
-      if (is_list(d)) Tbig += d * (d + 1) / 2;
+      if (i >= pl.M_grp && is_list(d)) Tbig += d * (d + 1) / 2;  // (grouped landmarks: k_schur_grp's)
     }
     pl.T = Tall;
     {
@@ -858,7 +936,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       big.reserve(Tbig);
       for (int i = 0; i < M; ++i) {
         const int64_t p0 = pl.lm_pair_ptr[i], p1 = pl.lm_pair_ptr[i + 1];
-        if (!is_list(p1 - p0)) continue;
+        if (i < pl.M_grp || !is_list(p1 - p0)) continue;
         for (int64_t p = p0; p < p1; ++p)
           for (int64_t q = p; q < p1; ++q)
             big.push_back({block_of(pl.pair_pose[p], pl.pair_pose[q]), {p, q}});
@@ -902,6 +980,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
     // d (d + 1) / 2 slots each, in (jj, kk) row-major order of the upper triangle
     pl.grp32.clear();
     pl.grp64.clear();
+    pl.grp128.clear();
     pl.grp_pat.clear();
     pl.lin_desc.clear();
     pl.n_apart2 = 0;
@@ -958,7 +1037,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       const int pieces = (gr.nl + grp_max - 1) / grp_max;
       const int per = (gr.nl + pieces - 1) / pieces;
       for (int c0 = 0; c0 < gr.nl; c0 += per) {
-        Plan::GrpDesc gd;
+        Plan::GrpDesc gd = Plan::GrpDesc();
         gd.l0 = gr.l0 + c0;
         gd.nl = std::min(per, gr.nl - c0);
         gd.d = gr.d;
@@ -971,7 +1050,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
             contrib.push_back({bk, (int32_t)pl.slot_blk.size()});
             pl.slot_blk.push_back(bk);
           }
-        (gr.d <= 5 ? pl.grp32 : pl.grp64).push_back(gd);
+        (gr.d <= 5 ? pl.grp32 : gr.d <= 10 ? pl.grp64 : pl.grp128).push_back(gd);
       }
     }
     const int sup_cap = schur_run_cap(M - pl.M_grp);

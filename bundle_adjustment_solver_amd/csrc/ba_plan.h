@@ -24,6 +24,11 @@ namespace ba {
 // the planner's big arrays (observation lists: 200 MB at BASELINE config C4) are
 // written exactly once, by parallel loops — a zero fill in front of that would touch
 // every page a first time on ONE thread.
+// Blocks of 4 MiB and more are 2 MiB-aligned and marked for transparent huge pages
+// (madvise): a 120 MB list then takes 60 page faults instead of 30 000 on its first touch.
+void *plan_big_alloc(size_t bytes);
+void plan_big_free(void *p, size_t bytes);
+constexpr size_t kPlanBigBytes = (size_t)4 << 20;
 template <class T>
 struct default_init_allocator : std::allocator<T> {
   template <class U>
@@ -31,6 +36,14 @@ struct default_init_allocator : std::allocator<T> {
     using other = default_init_allocator<U>;
   };
   using std::allocator<T>::allocator;
+  T *allocate(size_t n) {
+    if (n * sizeof(T) >= kPlanBigBytes) return (T *)plan_big_alloc(n * sizeof(T));
+    return std::allocator<T>::allocate(n);
+  }
+  void deallocate(T *p, size_t n) {
+    if (n * sizeof(T) >= kPlanBigBytes) return plan_big_free(p, n * sizeof(T));
+    std::allocator<T>::deallocate(p, n);
+  }
   template <class U, class... Args>
   void construct(U *p, Args &&...args) {
     if constexpr (sizeof...(Args) == 0)
@@ -76,7 +89,7 @@ constexpr int kSchurSuperChunks = 64;      // chunks per super-run (descriptor t
 // Covisibility groups (k_schur_grp): landmarks seen by the IDENTICAL set of
 // optimisable poses.  Their Schur contributions sum_i V_ji W_ki^T are one dense
 // (6d x 3n) (3n x 6d) product per group, which runs on the fp64 matrix cores.
-constexpr int kGrpMaxPoses = 10;    // pose-set sizes handled by the group kernel (<= 5: 32-wide tiles, <= 10: 64-wide)
+constexpr int kGrpMaxPoses = 20;    // pose-set sizes handled by the group kernels (k_schur_grp: <= 5: 32-wide image, <= 10: 64-wide, <= 20: 128-wide)
 constexpr int kGrpMinLandmarks = 24;  // smaller groups stay on the super-run path
 constexpr int kGrpMaxLandmarks = 1024; // landmarks per group workgroup (larger groups are split)
 constexpr int kGrpMaxObs = 32;        // observations per landmark of a group (one lane each in k_lin_grp)
@@ -110,6 +123,7 @@ struct Plan {
 
   // ---- landmark-major observations ----
   pvec<int32_t> obs_idx;          // n_obs*4: cam, pose_int, pt_int, pair|-1
+  pvec<int32_t> obs_cp;           // n_obs*2: cam | pose_int << 16, pt_int (k_cost's slim record; empty with >= 65536 cameras / poses)
   pvec<double> obs_uv;            // n_obs*2
   std::vector<int64_t> lm_obs_ptr;   // M+1
   // ---- pairs ----
@@ -171,10 +185,11 @@ struct Plan {
   std::vector<uint8_t> pair_pad;         // P: 1 = padded pair of a masked group (no observation)
   int64_t n_pair_pad = 0;
   std::vector<GrpRange> grp_range;
-  struct GrpDesc {                       // one k_schur_grp workgroup (64 bytes)
+  struct GrpDesc {                       // one k_schur_grp workgroup (128 bytes)
     int64_t p0;                          // first pair: pair(il, jj) = p0 + d * il + jj
     int32_t l0, nl, d, s0;               // landmarks, pose count, first of its d (d + 1) / 2 slots
     int32_t pose[kGrpMaxPoses];          // ascending optimised pose indices
+    int32_t pad_[6];
   };
   struct LinDesc {                       // one k_lin_grp workgroup (48 bytes): a run of landmarks of one group
     int64_t p0, o0;                      // pair(il, jj) = p0 + d * il + jj;  obs(il, oo) = o0 + no * il + oo
@@ -185,7 +200,7 @@ struct Plan {
   };
   std::vector<LinDesc> lin_desc;         // plain pieces [0, n_lin_plain), then the masked ones (pad_ = 1)
   int n_lin_plain = 0;
-  std::vector<GrpDesc> grp32, grp64;     // d <= 5 / 6 <= d <= 10
+  std::vector<GrpDesc> grp32, grp64, grp128;  // d <= 5 / 6 <= d <= 10 / 11 <= d <= 20
   // pattern entry of observation slot oo: {pose (internal index), camera | jj << 16 |
   // optimisable pose << 29 | last writer of its pair << 30}
   std::vector<int32_t> grp_pat;          // 2 ints per slot

@@ -164,9 +164,9 @@ int main(int argc, char **argv) {
       for (int l = gr.l0; l < gr.l0 + gr.nl; ++l) want_piece[l] = gr.d > 0;
     CHECK(next == pl.M_grp && pl.M_grp <= pl.M, "groups tile [0, M_grp)");
     std::vector<int> gcov(pl.M, 0);
-    for (const auto *list : {&pl.grp32, &pl.grp64})
+    for (const auto *list : {&pl.grp32, &pl.grp64, &pl.grp128})
       for (const auto &gd : *list) {
-        CHECK((gd.d <= 5) == (list == &pl.grp32), "group filed under the wrong tile width");
+        CHECK((gd.d <= 5) == (list == &pl.grp32) && (gd.d > 10) == (list == &pl.grp128), "group filed under the wrong tile width");
         CHECK(gd.nl >= 1 && gd.nl <= ba::kGrpMaxLandmarks && gd.l0 >= 0 && gd.l0 + gd.nl <= pl.M_grp, "group piece range");
         CHECK(gd.p0 == pl.lm_pair_ptr[gd.l0], "group pair base");
         for (int t = 1; t < gd.d; ++t) CHECK(gd.pose[t - 1] < gd.pose[t], "group poses ascend");
@@ -295,12 +295,18 @@ int main(int argc, char **argv) {
   for (size_t c = 0; c + 1 < pl.bchunk_lm.size(); ++c)
     CHECK(pl.bchunk_lm[c] < pl.bchunk_lm[c + 1] && pl.bchunk_lm[c + 1] - pl.bchunk_lm[c] <= ba::kSchurLandmarks,
           "backsub chunk size");
+  // the cost kernel's slim record mirrors the landmark-major list
+  CHECK(pl.obs_cp.size() == (size_t)pl.n_obs * 2, "slim record list size");
+  for (int64_t k = 0; k < pl.n_obs; ++k)
+    CHECK(pl.obs_cp[2 * k] == (pl.obs_idx[4 * k] | (pl.obs_idx[4 * k + 1] << 16)) && pl.obs_cp[2 * k + 1] == pl.obs_idx[4 * k + 2],
+          "slim record differs from the landmark-major record");
   // ---- checksum of every array the kernels consume: the test runs this program with
   // BA_PLAN_THREADS = 1 and = 7 and requires the same plan ----
   {
     auto mix = [](uint64_t h, uint64_t v) { return (h ^ v) * 0x100000001b3ull + (h >> 29); };
     uint64_t h = 1469598103934665603ull;
     for (auto v : pl.obs_idx) h = mix(h, (uint64_t)(uint32_t)v);
+    for (auto v : pl.obs_cp) h = mix(h, (uint64_t)(uint32_t)v);
     for (auto v : pl.obs_uv) { uint64_t b; memcpy(&b, &v, 8); h = mix(h, b); }
     for (auto v : pl.pair_pose) h = mix(h, (uint64_t)(uint32_t)v);
     for (auto v : pl.pair_lm) h = mix(h, (uint64_t)(uint32_t)v);
@@ -317,7 +323,7 @@ int main(int argc, char **argv) {
     std::printf("plan checksum %016llx\n", (unsigned long long)h);
   }
   std::printf("plan: M=%d (grouped %d in %zu+%zu pieces) P=%lld runs=%zu chunks=%zu triples=%lld (%lld in groups, +%lld big)  %s\n",
-              pl.M, pl.M_grp, pl.grp32.size(), pl.grp64.size(), (long long)pl.P, pl.sup_desc.size(),
+              pl.M, pl.M_grp, pl.grp32.size(), pl.grp64.size() + pl.grp128.size(), (long long)pl.P, pl.sup_desc.size(),
               pl.chunk_desc.size(), (long long)triples, (long long)grp_triples, (long long)big_triples,
               g_fail ? "FAILED" : "OK");
   return g_fail ? 1 : 0;

@@ -1166,9 +1166,8 @@ def test_off_path_configs_match_oracle(name, scale, built):
     info = g.get_schur_info()
     if name == "C4R":
         assert g.get_mask_info()["masked_landmarks"] > 0.5 * g.M_global
-    elif name == "W20":
-        assert info["grouped_landmarks"] == 0   # (a few landmarks near the fixed poses have
-        #                                          < 16 free poses and still fit a super-run)
+    elif name == "W20":   # 20-pose windows: covisibility groups with the 128-wide image (k_schur_grp_wide)
+        assert info["grouped_landmarks"] > 0.8 * g.M_global and info["groups64"] > 0
     else:
         assert g.get_dense_info()["fill"] > 0.9
 
@@ -1220,6 +1219,53 @@ def test_masked_superset_groups_match_oracle(kind, built, monkeypatch):
     for a, b in zip(rows, erows):
         assert a.iteration_status == b.iteration_status
         assert abs(a.trial_cost - b.trial_cost) <= 1e-11 * abs(b.trial_cost)
+
+
+@pytest.mark.parametrize("kind", ["mono20", "mono13", "stereo16", "mono20_dropout", "stereo14_dropout"])
+def test_wide_covisibility_groups_match_oracle(kind, built, monkeypatch):
+    """Pose sets of 11..20 poses (windows of 13 / 20 mono views, 14 / 16 stereo views:
+    up to 32 pattern slots): k_lin_grp with up to 20 poses per group, k_schur_grp_wide
+    (128-wide image, the four waves own nine of the 36 tiles each) and the group role
+    of k_backsub_update.  Blocks, reduced system and trajectory against the oracle, and
+    against the library's own plan without groups (BA_NO_GROUPS=1: super-runs / pose-
+    group classes / global triple list) to 1e-10."""
+    window = {"mono20": 20, "mono13": 13, "stereo16": 16, "mono20_dropout": 20, "stereo14_dropout": 14}[kind]
+    stereo = kind.startswith("stereo")
+    sc = scenes.synthetic_ba_scene(56, 5000, window, stereo, seed=61 + window, pixel_sigma=0.2,
+                                   dropout=0.15 if kind.endswith("dropout") else 0.0)
+    pr = scenes.scaled_problem(sc)
+    g, o = make_gpu(pr), O.Oracle(pr)
+    info = g.get_schur_info()
+    assert info["grouped_landmarks"] > 0.8 * g.M_global and info["groups64"] > 0, info
+    if kind.endswith("dropout"):
+        assert g.get_mask_info()["masked_landmarks"] > 0.3 * g.M_global
+    lam, hub = 1.5, 0.01
+    o.linearize(hub); o.damp_invert(lam); o.schur()
+    g.stage_linearize(lam, hub); g.stage_schur()
+    for (a, b) in zip(g.get_A() + g.get_C(), o.get_A() + o.get_C()):
+        assert blockwise_relerr(a, b) < RTOL_BLOCK
+    pi, pj, W = g.get_pairs()
+    opi, opj, oW = o.get_pairs()
+    key, okey = np.lexsort((pj, pi)), np.lexsort((opj, opi))
+    assert pi.shape == opi.shape and (pi[key] == opi[okey]).all() and (pj[key] == opj[okey]).all()
+    assert blockwise_relerr(W[key], oW[okey]) < RTOL_BLOCK
+    S, rhs = g.get_S()
+    oS, orhs = o.get_S()
+    assert relerr(S, oS) < 1e-9 and relerr(rhs, orhs) < 1e-9
+    assert relerr(g.stage_cost(), o.cost()) < 1e-12
+    kw = dict(max_iter=10, thr_step=0, thr_cost=0, huber=hub)
+    rows, _ = g.solve(make_options(**kw))
+    orows, _ = o.solve(O.make_options(**kw))
+    assert_same_trajectory(rows, orows)
+    ang, dt, dX = north_star_errors(g, o)
+    assert ang <= RTOL_FINAL and dt <= RTOL_FINAL and dX <= RTOL_FINAL, (ang, dt, dX)
+    monkeypatch.setenv("BA_NO_GROUPS", "1")
+    e = make_gpu(pr)
+    assert e.get_schur_info()["grouped_landmarks"] == 0
+    erows, _ = e.solve(make_options(**kw))
+    for a, b in zip(rows, erows):
+        assert a.iteration_status == b.iteration_status
+        assert abs(a.trial_cost - b.trial_cost) <= 1e-10 * abs(b.trial_cost)
 
 
 def test_dense_pattern_ordered_backward_sweep(built, monkeypatch):

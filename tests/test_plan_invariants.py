@@ -34,8 +34,12 @@ def plan_check(tmp_path_factory):
     (["30", "400", "5", "2"], {"BA_SUP_CAP": "7", "BA_NO_GROUPS": "1"}),         # tiny runs
     (["200", "6000", "3", "3"], {"BA_SUP_CAP": "1000", "BA_NO_GROUPS": "1"}),    # runs ended by the slot / chunk limits
     (["200", "6000", "3", "3"], {}),                        # groups beside super-runs (groups below 24 stay in runs)
-    (["60", "3000", "20", "1"], {}),                        # windows of 20 poses: landmarks split into pose-group classes
-    (["60", "3000", "20", "1"], {"BA_NO_SPLIT": "1"}),      # the same on the global triple list
+    (["60", "3000", "20", "1"], {}),                        # windows of 20 poses: 128-wide covisibility groups (11..20 poses)
+    (["60", "3000", "20", "1"], {"BA_NO_SPLIT": "1"}),      # (the ungrouped rest on the global triple list)
+    (["60", "3000", "20", "1"], {"BA_NO_GROUPS": "1"}),     # windows of 20 poses: landmarks split into pose-group classes
+    (["60", "3000", "20", "1"], {"BA_NO_GROUPS": "1", "BA_NO_SPLIT": "1"}),  # the same on the global triple list
+    (["60", "3000", "16", "2"], {}),                        # 16 stereo views: 32 pattern slots, 16 poses
+    (["60", "3000", "20", "1", "15"], {}),                  # 20-pose windows with dropout: masked wide groups
     (["90", "2000", "37", "2"], {"BA_NO_GROUPS": "1"}),     # four pose groups per landmark, ten classes
     (["120", "30000", "5", "2"], {"BA_LIN_STEPS": "2"}),    # many k_lin_grp pieces per group
     (["120", "30000", "5", "2"], {"BA_NO_LINGRP": "1"}),    # groups for the Schur kernel only
