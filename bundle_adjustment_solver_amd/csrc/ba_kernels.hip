@@ -1669,6 +1669,11 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the
+// global loads in flight (s_waitcnt vmcnt(0)): with the operands of the next two stages
+// requested just before it, every barrier would cost one memory latency (measured: 4.8-7 k
+// cycles per stage of k_schur_grp_wide).
+#define GW_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // Pose sets of 11..20 poses (6 d + 1 <= 121 columns: a 128-wide image, 36 upper 16x16
 // tiles).  144 accumulator registers per wave do not fit beside the staging arithmetic,
 // so here the four waves split the TILES, not the chunks: a stage = 4 x nlw landmarks
@@ -1687,6 +1692,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
   constexpr int IMG = (KRW / 2) * RS;
   __shared__ __attribute__((aligned(16))) double VA[IMG];
   __shared__ __attribute__((aligned(16))) double WB[IMG];
+#ifdef BA_GRP_DBG
+  __shared__ long long gdbg_s[256];
+  #ifndef BA_GRP_DBG_TID
+#define BA_GRP_DBG_TID 0
+#endif
+  const bool gdbg_on = blockIdx.x == 100 && threadIdx.x == BA_GRP_DBG_TID;
+  int gdbg_n = 0;
+#endif
+  GRP_STAMP()
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const DevProblem::GrpDesc *gp = grps + blockIdx.x;
@@ -1708,8 +1722,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
     VA[e] = 0.0;
     WB[e] = 0.0;
   }
-  double2 rw[2][6], rc[2][3];
-  double rb[2][3];
+  // operands of the NEXT stage, requested while this one is multiplied (one buffer: a two-
+  // deep ring made the compiler copy in-flight registers across the loop and wait for them)
+  double2 rw[1][6], rc[1][3];
+  double rb[1][3];
 #define GW_PREFETCH(B, st_)                                                         \
   {                                                                                 \
     const int c0_ = (st_) * per_stage;                                              \
@@ -1728,12 +1744,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
   // this wave's tiles: t < n_first: (ti, tj) = (wv, wv + t); else (7 - wv, 7 - wv + t - n_first)
   const int n_first = 8 - wv;
   GW_PREFETCH(0, 0)
-  if (nst > 1) GW_PREFETCH(1, 1)
 #define GW_IDX(k_, col_) (((k_) >> 1) * RS + (col_) * 2 + ((k_) & 1))
 #define GW_STAGE(B)                                                                 \
   {                                                                                 \
     const int c0 = st * per_stage;                                                  \
     const int nlc = min(per_stage, gnl - c0);                                       \
+    /* the stage's operands are waited for HERE, on every path: consumed only under \
+       the branch below, they would count as still in flight behind it and the next \
+       prefetch (which reuses their registers) would wait for ALL loads */           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) asm volatile("" : "+v"(rw[B][k_].x), "+v"(rw[B][k_].y)); \
+    _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) asm volatile("" : "+v"(rc[B][k_].x), "+v"(rc[B][k_].y), "+v"(rb[B][k_])); \
     if (il < nlw && li < nlc) {                                                     \
       const double k9[9] = {rw[B][0].x, rw[B][0].y, rw[B][1].x, rw[B][1].y, rw[B][2].x, \
                             rw[B][2].y, rw[B][3].x, rw[B][3].y, rw[B][4].x};        \
@@ -1765,6 +1785,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
         WB[GW_IDX(kb + 2, 6 * dd)] = rb[B][2];                                      \
       }                                                                             \
     }                                                                               \
+    GRP_STAMP()                                                                     \
     const int nks = (3 * nlc + 3) >> 2;                                             \
     if (nlc < per_stage) { /* partial last stage: stale rows up to the next multiple of four */ \
       for (int e = tid; e < (4 * nks - 3 * nlc) * TW; e += kBlock) {                \
@@ -1773,8 +1794,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
         WB[GW_IDX(k_, c_)] = 0.0;                                                   \
       }                                                                             \
     }                                                                               \
-    if (st + 2 < nst) GW_PREFETCH(B, st + 2)                                        \
-    __syncthreads();                                                                \
+    /* (unconditional, clamped: behind a branch the compiler's load counters merge the \
+        path without the prefetch and every stage waits for ALL loads in flight) */    \
+    GW_PREFETCH(B, min(st + 1, nst - 1))                                            \
+    GRP_STAMP()                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
+    GRP_STAMP()                                                                     \
+    GW_LDS_BARRIER();                                                                \
+    GRP_STAMP()                                                                     \
     {                                                                               \
       const double *ap = VA + (lk >> 1) * RS + lr * 2 + (lk & 1);                   \
       const double *bp = WB + (lk >> 1) * RS + lr * 2 + (lk & 1);                   \
@@ -1788,18 +1815,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
         }                                                                           \
       }                                                                             \
     }                                                                               \
-    __syncthreads();                                                                \
+    GRP_STAMP()                                                                     \
+    GW_LDS_BARRIER();                                                                \
+    GRP_STAMP()                                                                     \
     ++st;                                                                           \
   }
-  __syncthreads();
+  GW_LDS_BARRIER();
   for (int st = 0; st < nst;) {
     GW_STAGE(0)
-    if (st >= nst) break;
-    GW_STAGE(1)
   }
 #undef GW_STAGE
 #undef GW_IDX
 #undef GW_PREFETCH
+  GRP_STAMP()
   // every tile has one owner: the wave scatters its nine tiles to the group's slots
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -1823,6 +1851,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
       }
     }
   }
+  GRP_STAMP()
+#ifdef BA_GRP_DBG
+  if (gdbg_on) for (int q = 0; q < 256; ++q) g_grp_dbg[q] = q < gdbg_n ? gdbg_s[q] : 0;
+#endif
 }
 
 // Same sums for landmarks seen by more than kSchurPairs poses: one wave per

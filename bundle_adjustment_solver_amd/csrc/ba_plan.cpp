@@ -1034,7 +1034,11 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       }
       if (gr.d == 0) continue;  // no pair, no Schur contribution: no k_schur_grp workgroup
       static const int grp_max = getenv("BA_GRP_MAX") ? std::max(12, atoi(getenv("BA_GRP_MAX"))) : kGrpMaxLandmarks;
-      const int pieces = (gr.nl + grp_max - 1) / grp_max;
+      // (wide groups, d > 10: k_schur_grp_wide is bound by the fp64 matrix pipe — 27 MFMAs per
+      //  landmark — and a 20-pose window of a few hundred landmarks is one long workgroup:
+      //  pieces of <= kGrpWidePiece landmarks spread them over the CUs)
+      const int cap = gr.d > 10 ? std::min(grp_max, kGrpWidePiece) : grp_max;
+      const int pieces = (gr.nl + cap - 1) / cap;
       const int per = (gr.nl + pieces - 1) / pieces;
       for (int c0 = 0; c0 < gr.nl; c0 += per) {
         Plan::GrpDesc gd = Plan::GrpDesc();

@@ -92,6 +92,7 @@ constexpr int kSchurSuperChunks = 64;      // chunks per super-run (descriptor t
 constexpr int kGrpMaxPoses = 20;    // pose-set sizes handled by the group kernels (k_schur_grp: <= 5: 32-wide image, <= 10: 64-wide, <= 20: 128-wide)
 constexpr int kGrpMinLandmarks = 24;  // smaller groups stay on the super-run path
 constexpr int kGrpMaxLandmarks = 1024; // landmarks per group workgroup (larger groups are split)
+constexpr int kGrpWidePiece = 104;    // landmarks per k_schur_grp_wide workgroup (13 stages of 8)
 constexpr int kGrpMaxObs = 32;        // observations per landmark of a group (one lane each in k_lin_grp)
 constexpr int kLinGrpSteps = 24;      // wave steps per k_lin_grp workgroup (landmarks: 4 waves x nlw x steps)
 inline int lin_grp_nlw(int no) { return 64 / no < 7 ? 64 / no : 7; }  // landmarks per wave step
