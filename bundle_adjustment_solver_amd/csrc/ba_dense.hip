@@ -292,6 +292,13 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
         BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(ng - nf), dim3(256), s, L, ld,     \
                   tg0 + nf, dd.tgt_desc, dd.src_t, done);                                   \
     }                                                                                       \
+  } else if (dag) {                                                                         \
+    /* three-kernel path: every non-tail level in ONE dataflow launch with lookahead */     \
+    BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_dag, dim3(dd.n_dag_items), dim3(256), s, L, ld,     \
+              row_limit, (const int2 *)dd.dag_items, dd.n_dag_items, dd.item_t, dd.item_I,  \
+              dd.dag_ntrsm, Ldiag, dd.tgt_desc, dd.src_t, dd.upd_pre, dd.col_need, done,    \
+              bad, dd.fwd_flags, dd.dag_dflags, dd.dag_tcnt, dd.fwd_cnt, dd.fwd_ticket,     \
+              gen_now);                                                                     \
   } else if (fwd_flow) {                                                                    \
     /* every non-tail level — factorisation + TRSM and updates — in ONE dataflow launch */  \
     BA_LAUNCH(K_CHOL_DIAG_TRSM, NS::k_chol_fwd_flow, dim3(dd.n_fwd_items), dim3(256), s, L, \
@@ -345,13 +352,13 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
               npad, dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, \
               x, dd.col_x, done, dd.flow_flags,                                             \
               (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad, \
-              fwd_flow ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
+              (fwd_flow || dag) ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
   } else if (flow_back && n_back > 0) {                                                     \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow<false>, dim3(n_back), dim3(256), s, L, ld, npad, \
               dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, x,    \
               dd.col_x, done, dd.flow_flags,                                                \
               (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad, \
-              fwd_flow ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
+              (fwd_flow || dag) ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
   } else                                                                                    \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
@@ -416,6 +423,38 @@ bool dense_fwd_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
   return true;
 }
 
+bool dense_dag_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &items,
+                     std::vector<int> &pre, std::vector<int> &need, std::vector<int> &ntrsm) {
+  const bool fused = sc.fused_ok && dd.f_desc && dd.want_fused;
+  const bool split = dd.want_split || !dd.row_desc || sc.max_rows > 4 * (4 / (sc.nb / 16));
+  const int tail_levels = dense_tail_levels(sc, dd, fused, nullptr);
+  const int nlv = sc.nlev - tail_levels;
+  items.clear();
+  pre.assign(std::max<size_t>(1, sc.tgt_J.size()), 0);
+  need.assign((size_t)sc.ncb + 1, 0);
+  ntrsm.assign((size_t)sc.ncb + 1, 0);
+  if (fused || !split || nlv < 2 || (int)sc.tgt_first.size() < sc.nlev) return false;
+  for (size_t q = 0; q < sc.item_t.size(); ++q) ++ntrsm[sc.item_t[q]];
+  auto push = [&](int kind, int id) {
+    items.push_back(kind);
+    items.push_back(id);
+  };
+  auto tiles_of = [&](int l) {
+    for (int t = sc.lev_ptr[l]; t < sc.lev_ptr[l + 1]; ++t) push(0, t);
+    for (int q = sc.item_ptr[l]; q < sc.item_ptr[l + 1]; ++q) push(1, q);
+  };
+  tiles_of(0);
+  for (int l = 0; l < nlv; ++l) {
+    const int tg0 = sc.tgt_ptr[l], tg1 = sc.tgt_ptr[l + 1], nf = sc.tgt_first[l];
+    for (int tg = tg0; tg < tg1; ++tg) pre[tg] = need[sc.tgt_J[tg]];  // (updates of EARLIER levels)
+    for (int tg = tg0; tg < tg0 + nf; ++tg) push(2, tg);
+    if (l + 1 < nlv) tiles_of(l + 1);  // the next level's tiles beside the bulk of this level's update
+    for (int tg = tg0 + nf; tg < tg1; ++tg) push(2, tg);
+    for (int tg = tg0; tg < tg1; ++tg) ++need[sc.tgt_J[tg]];
+  }
+  return true;
+}
+
 void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                         const int *done, const DenseSchedule &sc,
                         const DenseDev &dd, hipStream_t s) {
@@ -468,6 +507,11 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   // see DenseDev::want_fwd_flow); its counters are zeroed again by the backward launch
   const bool fwd_flow = flow && !split && !look && dd.want_fwd_flow && dd.fwd_flags && dd.fwd_items &&
                         dd.n_fwd_items > 0 && dd.fwd_cnt && n_back > 0;
+  // the three-kernel path (dense patterns) as one dataflow launch with lookahead (BA_DENSE_DAG=0:
+  // three launches per level)
+  const bool dag = flow && split && !look && dd.want_dag && dd.dag_items && dd.n_dag_items > 0 &&
+                   (dd.n_dag_items <= DenseDev::kDagMaxItems || dd.force_dag) &&
+                   dd.fwd_flags && dd.fwd_cnt && dd.dag_dflags && dd.dag_tcnt && n_back > 0;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

@@ -295,6 +295,19 @@ struct DenseDev {
   // on one stream cost less than the polling workgroups of the later levels, which hold
   // their CU slots from the start of the launch
   bool want_fwd_flow = false;
+  // forward sweep of the three-kernel path as one dataflow launch with lookahead (k_chol_dag):
+  // items {kind, index}, TRSM items per position, "tile factorised" flags, per-column
+  // counters of finished TRSM items (shares upd_pre / col_need / fwd_cnt / fwd_flags / fwd_ticket)
+  int *dag_items = nullptr, *dag_ntrsm = nullptr, *dag_dflags = nullptr, *dag_tcnt = nullptr;
+  int n_dag_items = 0;
+  // BA_DENSE_DAG=0: three launches per level; =1: also beyond kDagMaxItems.  Measured (MI355X):
+  // moderately filled patterns gain — C1 0.304 -> 0.286 ms per iteration (forward sweep 188 ->
+  // 145 us), W20 367 -> 303 us —, DENSE patterns LOSE: DENSE1K 5.5 -> 7.1 ms, n = 5 970 5.1 ->
+  // 6.2 ms: 145 k update workgroups of ~3 us each pay ticket + descriptor + poll + late
+  // target load (~5 us of dependent latency) at 2-3 workgroups per CU (the launch carries
+  // the tile kernel's registers and LDS) against 4+ for the plain update kernel
+  bool want_dag = true, force_dag = false;
+  static constexpr int kDagMaxItems = 16384;
   int n_flow = 0, flow_tail_t0 = 0;
   mutable int flow_gen = 0;
   bool flow_ok = true;  // false while a hipGraph is captured / replayed (the generation is a kernel argument)
@@ -318,6 +331,9 @@ struct DenseDev {
     want_flow = !(fl && fl[0] == '0');
     const char *ff = getenv("BA_DENSE_FWD_FLOW");
     want_fwd_flow = ff && ff[0] == '1';
+    const char *dg = getenv("BA_DENSE_DAG");
+    want_dag = !(dg && dg[0] == '0');
+    force_dag = dg && dg[0] == '1';
     const char *tk = getenv("BA_DENSE_TICKET");
     force_ticket = tk && tk[0] == '1';
     const char *la = getenv("BA_DENSE_LOOKAHEAD");
@@ -338,6 +354,10 @@ int dense_flow_order(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
 // the target's column, need[p] = all updates on position p's column; false if the path does not apply
 bool dense_fwd_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &items,
                      std::vector<int> &pre, std::vector<int> &need);
+// the same for the three-kernel path (k_chol_dag): kinds 0 tile / 1 TRSM item / 2 update target in
+// lookahead order, ntrsm[p] = TRSM items of position p
+bool dense_dag_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &items,
+                     std::vector<int> &pre, std::vector<int> &need, std::vector<int> &ntrsm);
 void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
                        const int *zt_J, int n_zt, int nb, const int *done_flag,
                        hipStream_t s);

@@ -1290,6 +1290,47 @@ def test_dense_pattern_ordered_backward_sweep(built, monkeypatch):
         assert abs(a.trial_cost - b.trial_cost) <= 1e-9 * abs(b.trial_cost)
 
 
+@pytest.mark.parametrize("scene", ["dense170", "window20", "c1"])
+def test_dag_forward_sweep_equals_the_three_launches_per_level(scene, built, monkeypatch):
+    """Patterns with many row tiles per column take the three-kernel path (k_chol_diag /
+    k_chol_trsm / k_chol_update).  Its forward sweep runs as ONE dataflow launch over all
+    levels with lookahead (k_chol_dag: tiles, TRSM items and update targets as tickets; the
+    next level's tiles ahead of the bulk of this level's update); BA_DENSE_DAG=0 keeps the
+    three launches per level: same arithmetic in the same order, so the trajectories agree
+    bit for bit; with forced re-use of the handle (second solve: counters and flags of the
+    first are reset / superseded by the generation number)."""
+    if scene == "dense170":
+        sc = scenes.dense_covisibility_scene(170, 5000, 8, seed=51)
+    elif scene == "window20":
+        sc = scenes.synthetic_ba_scene(120, 9000, 20, False, seed=52, pixel_sigma=0.2)
+    else:
+        sc = scenes.config_scene("C1")
+    pr = scenes.scaled_problem(sc)
+    opt = dict(max_iter=6, thr_step=0, thr_cost=0)
+    runs = []
+    for env in ({"BA_DENSE_DAG": "1"}, {"BA_DENSE_DAG": "0"}):   # (1: also beyond the item limit of the default)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = make_gpu(pr)
+        rows, _ = g.solve(make_options(**opt))
+        assert g.get_dropped_pivots() == 0
+        P1 = g.get_poses().copy()
+        g.update_values(pr["pose_T"], pr["pt_X"])
+        rows2, _ = g.solve(make_options(**opt))
+        assert [(r.iteration_status, r.trial_cost) for r in rows] == [(r.iteration_status, r.trial_cost) for r in rows2]
+        assert (g.get_poses() == P1).all()
+        runs.append(([(r.iteration_status, r.trial_cost, r.damping_term) for r in rows], P1, g.get_points()[0].copy()))
+        for k in env:
+            monkeypatch.delenv(k)
+    assert runs[0][0] == runs[1][0]
+    assert (runs[0][1] == runs[1][1]).all() and (runs[0][2] == runs[1][2]).all()
+    if scene == "dense170":
+        o = O.Oracle(pr)
+        orows, _ = o.solve(O.make_options(**opt))
+        for a, b in zip(runs[0][0], orows):
+            assert a[0] == b.iteration_status and relerr(a[1], b.trial_cost) < 1e-7
+
+
 def test_update_values_resolves_without_replanning(built):
     """ba_update_values (new values, same structure): after a solve the problem is
     re-seeded with its ORIGINAL values and solved again — the second trajectory and
