@@ -687,13 +687,13 @@ int ba_finalize(ba_handle *h) {
           return -1;
         HIP_TRY(hipMemset(dd.fwd_cnt, 0, need.size() * sizeof(int)));
       }
-      std::vector<int> ntrsm;
-      if (ba::dense_dag_items(sc, dd, items, pre, need, ntrsm)) {
+      std::vector<int> ntrsm, lneed;
+      if (ba::dense_dag_items(sc, dd, items, pre, need, ntrsm, lneed)) {
         dd.n_dag_items = (int)items.size() / 2;
         dd.n_fwd_cnt = (int)need.size();
         if (times) fprintf(stderr, "[finalize] k_chol_dag: %d items\n", dd.n_dag_items);
         if (h->upload(&dd.dag_items, items) || h->upload(&dd.upd_pre, pre) || h->upload(&dd.col_need, need) ||
-            h->upload(&dd.dag_ntrsm, ntrsm) || h->dalloc(&dd.fwd_cnt, need.size()) ||
+            h->upload(&dd.dag_ntrsm, ntrsm) || h->upload(&dd.look_need, lneed) || h->dalloc(&dd.fwd_cnt, need.size()) ||
             h->dalloc(&dd.dag_dflags, need.size()) || h->dalloc(&dd.dag_tcnt, need.size()))
           return -1;
         HIP_TRY(hipMemset(dd.fwd_cnt, 0, need.size() * sizeof(int)));
@@ -1458,11 +1458,13 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
       HIP_TRY(hipMalloc((void **)&dd.fwd_cnt, need.size() * sizeof(int)));
       HIP_TRY(hipMemset(dd.fwd_cnt, 0, need.size() * sizeof(int)));
     }
-    std::vector<int> ntrsm;
-    if (ba::dense_dag_items(sc, dd, items, pre, need, ntrsm)) {
+    std::vector<int> ntrsm, lneed;
+    if (ba::dense_dag_items(sc, dd, items, pre, need, ntrsm, lneed)) {
       dd.n_dag_items = (int)items.size() / 2;
       dd.n_fwd_cnt = (int)need.size();
-      if (up(&dd.dag_items, items) || up(&dd.upd_pre, pre) || up(&dd.col_need, need) || up(&dd.dag_ntrsm, ntrsm)) return -1;
+      if (up(&dd.dag_items, items) || up(&dd.upd_pre, pre) || up(&dd.col_need, need) || up(&dd.dag_ntrsm, ntrsm) ||
+          up(&dd.look_need, lneed))
+        return -1;
       for (int **q : {&dd.fwd_cnt, &dd.dag_dflags, &dd.dag_tcnt}) {
         HIP_TRY(hipMalloc((void **)q, need.size() * sizeof(int)));
         HIP_TRY(hipMemset(*q, 0, need.size() * sizeof(int)));
@@ -1496,7 +1498,7 @@ int ba_dense_spd_solve(ba_handle *h, int n, const double *A, const double *b,
                   (void *)dd.flow_ticket, (void *)dd.bad_pivots, (void *)dd.fwd_flags,
                   (void *)dd.fwd_ticket, (void *)dd.fwd_items, (void *)dd.upd_pre, (void *)dd.col_need,
                   (void *)dd.fwd_cnt, (void *)dd.dag_items, (void *)dd.dag_ntrsm, (void *)dd.dag_dflags,
-                  (void *)dd.dag_tcnt})
+                  (void *)dd.dag_tcnt, (void *)dd.look_need})
     (void)hipFree(p);
   HIP_TRY(hipGetLastError());
   if (bad_h >= ba::kFlowTimeout) return fail("ba_dense_spd_solve: a dataflow hand-off timed out");

@@ -292,6 +292,31 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
         BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(ng - nf), dim3(256), s, L, ld,     \
                   tg0 + nf, dd.tgt_desc, dd.src_t, done);                                   \
     }                                                                                       \
+  } else if (look2) {                                                                       \
+    /* dense patterns: lookahead inside one launch per level (k_chol_look) */               \
+    const int nlv = sc.nlev - tail_levels;                                                  \
+    {                                                                                       \
+      const int t0 = sc.lev_ptr[0], nt = sc.lev_ptr[1] - t0;                                \
+      const int it0 = sc.item_ptr[0], ni = sc.item_ptr[1] - it0;                            \
+      BA_LAUNCH(K_CHOL_DIAG, NS::k_chol_diag, dim3(nt), dim3(256), s, L, ld, t0, Ldiag, done, bad); \
+      if (ni > 0)                                                                           \
+        BA_LAUNCH(K_CHOL_TRSM, NS::k_chol_trsm, dim3(ni), dim3(NS::NP * 64), s, L, ld,      \
+                  row_limit, it0, dd.item_t, dd.item_I, Ldiag, done);                       \
+    }                                                                                       \
+    for (int l = 0; l < nlv; ++l) {                                                         \
+      const int tg0 = sc.tgt_ptr[l], ng = sc.tgt_ptr[l + 1] - tg0, nf = sc.tgt_first[l];    \
+      if (l + 1 < nlv) {                                                                    \
+        const int t1 = sc.lev_ptr[l + 1], nt1 = sc.lev_ptr[l + 2] - t1;                     \
+        const int it1 = sc.item_ptr[l + 1], ni1 = sc.item_ptr[l + 2] - it1;                 \
+        BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_look, dim3(nt1 + ni1 + ng), dim3(256), s, L,    \
+                  ld, row_limit, nf, t1, nt1, it1, ni1, tg0, dd.item_t, dd.item_I, Ldiag,   \
+                  dd.tgt_desc, dd.src_t, dd.look_need, done, bad, dd.dag_dflags,            \
+                  dd.fwd_cnt, gen_now);                                                     \
+      } else if (ng > 0) {                                                                  \
+        BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_update, dim3(ng), dim3(256), s, L, ld, tg0,     \
+                  dd.tgt_desc, dd.src_t, done);                                             \
+      }                                                                                     \
+    }                                                                                       \
   } else if (dag) {                                                                         \
     /* three-kernel path: every non-tail level in ONE dataflow launch with lookahead */     \
     BA_LAUNCH(K_CHOL_UPDATE, NS::k_chol_dag, dim3(dd.n_dag_items), dim3(256), s, L, ld,     \
@@ -352,13 +377,13 @@ void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
               npad, dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, \
               x, dd.col_x, done, dd.flow_flags,                                             \
               (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad, \
-              (fwd_flow || dag) ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
+              (fwd_flow || dag || look2) ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
   } else if (flow_back && n_back > 0) {                                                     \
     BA_LAUNCH(K_CHOL_BACK, NS::k_chol_back_flow<false>, dim3(n_back), dim3(256), s, L, ld, npad, \
               dd.flow_order, n_back, back_t_end, dd.back_desc, dd.rows, Ldiag, dd.xc, x,    \
               dd.col_x, done, dd.flow_flags,                                                \
               (n_back <= kFlowResident && !dd.force_ticket) ? nullptr : dd.flow_ticket, gen_now, bad, \
-              (fwd_flow || dag) ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
+              (fwd_flow || dag || look2) ? dd.fwd_cnt : nullptr, dd.n_fwd_cnt);                               \
   } else                                                                                    \
   for (int l = sc.nlev - tail_levels - 1; l >= 0; --l) {                                    \
     const int t0 = sc.lev_ptr[l], nt = sc.lev_ptr[l + 1] - t0;                              \
@@ -424,7 +449,8 @@ bool dense_fwd_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
 }
 
 bool dense_dag_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &items,
-                     std::vector<int> &pre, std::vector<int> &need, std::vector<int> &ntrsm) {
+                     std::vector<int> &pre, std::vector<int> &need, std::vector<int> &ntrsm,
+                     std::vector<int> &look_need) {
   const bool fused = sc.fused_ok && dd.f_desc && dd.want_fused;
   const bool split = dd.want_split || !dd.row_desc || sc.max_rows > 4 * (4 / (sc.nb / 16));
   const int tail_levels = dense_tail_levels(sc, dd, fused, nullptr);
@@ -433,6 +459,7 @@ bool dense_dag_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
   pre.assign(std::max<size_t>(1, sc.tgt_J.size()), 0);
   need.assign((size_t)sc.ncb + 1, 0);
   ntrsm.assign((size_t)sc.ncb + 1, 0);
+  look_need.assign((size_t)sc.ncb + 1, 0);
   if (fused || !split || nlv < 2 || (int)sc.tgt_first.size() < sc.nlev) return false;
   for (size_t q = 0; q < sc.item_t.size(); ++q) ++ntrsm[sc.item_t[q]];
   auto push = [&](int kind, int id) {
@@ -447,7 +474,10 @@ bool dense_dag_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
   for (int l = 0; l < nlv; ++l) {
     const int tg0 = sc.tgt_ptr[l], tg1 = sc.tgt_ptr[l + 1], nf = sc.tgt_first[l];
     for (int tg = tg0; tg < tg1; ++tg) pre[tg] = need[sc.tgt_J[tg]];  // (updates of EARLIER levels)
-    for (int tg = tg0; tg < tg0 + nf; ++tg) push(2, tg);
+    for (int tg = tg0; tg < tg0 + nf; ++tg) {
+      push(2, tg);
+      ++look_need[sc.tgt_J[tg]];  // (k_chol_look: the "first" targets of the level before the tile's)
+    }
     if (l + 1 < nlv) tiles_of(l + 1);  // the next level's tiles beside the bulk of this level's update
     for (int tg = tg0 + nf; tg < tg1; ++tg) push(2, tg);
     for (int tg = tg0; tg < tg1; ++tg) ++need[sc.tgt_J[tg]];
@@ -510,8 +540,13 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
   // the three-kernel path (dense patterns) as one dataflow launch with lookahead (BA_DENSE_DAG=0:
   // three launches per level)
   const bool dag = flow && split && !look && dd.want_dag && dd.dag_items && dd.n_dag_items > 0 &&
-                   (dd.n_dag_items <= DenseDev::kDagMaxItems || dd.force_dag) &&
+                   (dd.n_dag_items <= DenseDev::kDagMaxItems || dd.force_dag) && !dd.force_look2 &&
                    dd.fwd_flags && dd.fwd_cnt && dd.dag_dflags && dd.dag_tcnt && n_back > 0;
+  // ... and beyond that item count: lookahead inside one launch per level (BA_DENSE_LOOK2=0: off)
+  const bool look2 = flow && split && !look && !dag && dd.want_look2 && dd.dag_dflags && dd.look_need &&
+                     dd.fwd_cnt &&
+                     sc.nlev - tail_levels >= 3 &&
+                     (int)sc.tgt_first.size() >= sc.nlev;
   if (sc.nb == 32) {
     BA_DENSE_RUN(nb32)
   } else {

@@ -299,6 +299,7 @@ struct DenseDev {
   // items {kind, index}, TRSM items per position, "tile factorised" flags, per-column
   // counters of finished TRSM items (shares upd_pre / col_need / fwd_cnt / fwd_flags / fwd_ticket)
   int *dag_items = nullptr, *dag_ntrsm = nullptr, *dag_dflags = nullptr, *dag_tcnt = nullptr;
+  int *look_need = nullptr;  // k_chol_look: per position, the previous level's targets in its column
   int n_dag_items = 0;
   // BA_DENSE_DAG=0: three launches per level; =1: also beyond kDagMaxItems.  Measured (MI355X):
   // moderately filled patterns gain — C1 0.304 -> 0.286 ms per iteration (forward sweep 188 ->
@@ -306,6 +307,7 @@ struct DenseDev {
   // 6.2 ms: 145 k update workgroups of ~3 us each pay ticket + descriptor + poll + late
   // target load (~5 us of dependent latency) at 2-3 workgroups per CU (the launch carries
   // the tile kernel's registers and LDS) against 4+ for the plain update kernel
+  bool want_look2 = true, force_look2 = false;  // BA_DENSE_LOOK2=0: no in-launch lookahead on dense patterns; =1: instead of k_chol_dag too
   bool want_dag = true, force_dag = false;
   static constexpr int kDagMaxItems = 16384;
   int n_flow = 0, flow_tail_t0 = 0;
@@ -334,6 +336,9 @@ struct DenseDev {
     const char *dg = getenv("BA_DENSE_DAG");
     want_dag = !(dg && dg[0] == '0');
     force_dag = dg && dg[0] == '1';
+    const char *l2 = getenv("BA_DENSE_LOOK2");
+    want_look2 = !(l2 && l2[0] == '0');
+    force_look2 = l2 && l2[0] == '1';
     const char *tk = getenv("BA_DENSE_TICKET");
     force_ticket = tk && tk[0] == '1';
     const char *la = getenv("BA_DENSE_LOOKAHEAD");
@@ -357,7 +362,8 @@ bool dense_fwd_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
 // the same for the three-kernel path (k_chol_dag): kinds 0 tile / 1 TRSM item / 2 update target in
 // lookahead order, ntrsm[p] = TRSM items of position p
 bool dense_dag_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<int> &items,
-                     std::vector<int> &pre, std::vector<int> &need, std::vector<int> &ntrsm);
+                     std::vector<int> &pre, std::vector<int> &need, std::vector<int> &ntrsm,
+                     std::vector<int> &look_need);
 void launch_dense_init(double *L, int ld, const int *col_x, const int *zt_I,
                        const int *zt_J, int n_zt, int nb, const int *done_flag,
                        hipStream_t s);

@@ -1308,7 +1308,10 @@ def test_dag_forward_sweep_equals_the_three_launches_per_level(scene, built, mon
     pr = scenes.scaled_problem(sc)
     opt = dict(max_iter=6, thr_step=0, thr_cost=0)
     runs = []
-    for env in ({"BA_DENSE_DAG": "1"}, {"BA_DENSE_DAG": "0"}):   # (1: also beyond the item limit of the default)
+    # (DAG=1: also beyond the item limit of the default; LOOK2=1: the in-launch lookahead that
+    #  dense patterns beyond that limit take — k_chol_look: the next level's tiles and TRSM
+    #  items beside the bulk of this level's update, two launches per level)
+    for env in ({"BA_DENSE_DAG": "1"}, {"BA_DENSE_LOOK2": "1"}, {"BA_DENSE_DAG": "0", "BA_DENSE_LOOK2": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g = make_gpu(pr)
@@ -1322,8 +1325,9 @@ def test_dag_forward_sweep_equals_the_three_launches_per_level(scene, built, mon
         runs.append(([(r.iteration_status, r.trial_cost, r.damping_term) for r in rows], P1, g.get_points()[0].copy()))
         for k in env:
             monkeypatch.delenv(k)
-    assert runs[0][0] == runs[1][0]
-    assert (runs[0][1] == runs[1][1]).all() and (runs[0][2] == runs[1][2]).all()
+    for other in runs[1:]:
+        assert runs[0][0] == other[0]
+        assert (runs[0][1] == other[1]).all() and (runs[0][2] == other[2]).all()
     if scene == "dense170":
         o = O.Oracle(pr)
         orows, _ = o.solve(O.make_options(**opt))
