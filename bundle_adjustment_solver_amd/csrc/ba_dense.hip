@@ -432,18 +432,23 @@ bool dense_fwd_items(const DenseSchedule &sc, const DenseDev &dd, std::vector<in
   pre.assign(std::max<size_t>(1, sc.tgt_J.size()), 0);
   need.assign((size_t)sc.ncb + 1, 0);
   if (fused || split || nlv < 2) return false;
+  auto push = [&](int kind, int id) {
+    items.push_back(kind);
+    items.push_back(id);
+  };
+  // LOOKAHEAD order (as k_chol_dag): the targets of level l in a column of level l + 1 first,
+  // then the tiles of level l + 1, then the rest of level l's targets
+  const bool ahead = (int)sc.tgt_first.size() >= sc.nlev;
+  for (int t = sc.lev_ptr[0]; t < sc.lev_ptr[1]; ++t) push(0, t);
   for (int l = 0; l < nlv; ++l) {
-    for (int t = sc.lev_ptr[l]; t < sc.lev_ptr[l + 1]; ++t) {
-      items.push_back(0);
-      items.push_back(t);
-    }
+    const int tg0 = sc.tgt_ptr[l], tg1 = sc.tgt_ptr[l + 1], nf = ahead ? sc.tgt_first[l] : tg1 - tg0;
     // (targets of one level on one column do not wait for each other: count after the level)
-    for (int tg = sc.tgt_ptr[l]; tg < sc.tgt_ptr[l + 1]; ++tg) {
-      pre[tg] = need[sc.tgt_J[tg]];
-      items.push_back(1);
-      items.push_back(tg);
-    }
-    for (int tg = sc.tgt_ptr[l]; tg < sc.tgt_ptr[l + 1]; ++tg) ++need[sc.tgt_J[tg]];
+    for (int tg = tg0; tg < tg1; ++tg) pre[tg] = need[sc.tgt_J[tg]];
+    for (int tg = tg0; tg < tg0 + nf; ++tg) push(1, tg);
+    if (l + 1 < nlv)
+      for (int t = sc.lev_ptr[l + 1]; t < sc.lev_ptr[l + 2]; ++t) push(0, t);
+    for (int tg = tg0 + nf; tg < tg1; ++tg) push(1, tg);
+    for (int tg = tg0; tg < tg1; ++tg) ++need[sc.tgt_J[tg]];
   }
   return true;
 }

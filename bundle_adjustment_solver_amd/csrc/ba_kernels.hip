@@ -1545,7 +1545,9 @@ __global__ __launch_bounds__(kBlock, (NT == 2 && BA_GRP_KRW <= 24) ? 3 : 2) void
     GRP_STAMP()                                                                     \
     const int nlc = min(nlw, gd.nl - ch * nlw);                                     \
     if (il < nlc) {                                                                 \
-      /* W_p (6x3) from its compact record, V_p = W_p Cinv_i */                     \
+      /* W_p (6x3) from its compact record, V_p = W_p Cinv_i (fused multiply-adds: the fp64 \
+         VALU shares its pipe with the fp64 MFMA on this part, every instruction counts) */ \
+      _Pragma("clang fp contract(fast)")                                            \
       const double k9[9] = {rw[B][0].x, rw[B][0].y, rw[B][1].x, rw[B][1].y, rw[B][2].x, \
                             rw[B][2].y, rw[B][3].x, rw[B][3].y, rw[B][4].x};        \
       const double x0 = rw[B][4].y, x1 = rw[B][5].x, x2 = rw[B][5].y;               \
@@ -1755,6 +1757,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_schur_grp_wide(DevProblem d, cons
     _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) asm volatile("" : "+v"(rw[B][k_].x), "+v"(rw[B][k_].y)); \
     _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) asm volatile("" : "+v"(rc[B][k_].x), "+v"(rc[B][k_].y), "+v"(rb[B][k_])); \
     if (il < nlw && li < nlc) {                                                     \
+      _Pragma("clang fp contract(fast)")                                            \
       const double k9[9] = {rw[B][0].x, rw[B][0].y, rw[B][1].x, rw[B][1].y, rw[B][2].x, \
                             rw[B][2].y, rw[B][3].x, rw[B][3].y, rw[B][4].x};        \
       const double x0 = rw[B][4].y, x1 = rw[B][5].x, x2 = rw[B][5].y;               \
