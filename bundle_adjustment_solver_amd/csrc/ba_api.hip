@@ -100,9 +100,23 @@ int enqueue_iteration(ba_handle *h) {
   if (!direct) ba::launch_scatter(d, s);
   ba::launch_dense_solve(d, h->sched, h->ddev, s);
   mark(h, 3);
-  ba::launch_backsub_update(d, s, no_side);  // trial parameters, model terms, step norms
+  // (single GPU, every free landmark grouped: back-substitution and trial-point linearisation
+  //  as roles of ONE launch — k_backsub_lin.  OPT-IN, BA_FUSE_BL=1: measured on MI355X the
+  //  interleaved roles do not fill each other's idle pipes — both kernels run two waves per
+  //  SIMD and are bound by the latency those two waves cannot hide, mixing them adds no wave:
+  //  C4 172.6 us with the roles one after the other (= 68.8 + 104, one launch gap saved: 0.4245
+  //  vs 0.428 ms per iteration), 177 / 189 / 203 / 227 us with a lead of 640 / 320 / 160 / 64
+  //  pieces.  Not under a captured graph: the generation number is a kernel argument)
+  static const bool fuse_env = getenv("BA_FUSE_BL") && getenv("BA_FUSE_BL")[0] == '1';
+  const bool fuse_bl = no_side && fuse_env && !h->use_graph && ba::can_fuse_backsub_lin(d) && h->ddev.bad_pivots;
+  if (fuse_bl)
+    ba::launch_backsub_lin(d, s, true, ++h->bl_gen, h->ddev.bad_pivots);
+  else
+    ba::launch_backsub_update(d, s, no_side);  // trial parameters, model terms, step norms
   mark(h, 4);
-  if (no_side) {
+  if (fuse_bl) {
+    h->tiles_ready = true;
+  } else if (no_side) {
     h->tiles_ready = true;
     ba::launch_lin_landmarks(d, 1, s);
   } else if (ov) {
@@ -524,6 +538,12 @@ int ba_finalize(ba_handle *h) {
       return -1;
     h->kind(2);
     if (h->dalloc(&d.Apart2, (size_t)pl.n_apart2 * 27) || h->dalloc(&d.lin_dump, (size_t)ba::kLinDump)) return -1;
+    h->kind(0);
+    if (h->dalloc(&d.bl_flag, pl.lin_desc.size() + 1) || h->dalloc(&d.pose_flag, (size_t)ba::kPoseGrid)) return -1;
+    HIP_TRY(hipMemset(d.bl_flag, 0, (pl.lin_desc.size() + 1) * sizeof(int)));
+    HIP_TRY(hipMemset(d.pose_flag, 0, (size_t)ba::kPoseGrid * sizeof(int)));
+    h->bl_gen = 0;
+    h->kind(2);
     if (!pl.grp_pat.empty())
       HIP_TRY(hipMemcpy(d.grp_pat, pl.grp_pat.data(), pl.grp_pat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (pl.n_apart2 > 0) HIP_TRY(hipMemset(d.Apart2, 0, (size_t)pl.n_apart2 * 27 * sizeof(double)));
@@ -1283,7 +1303,7 @@ const char *ba_kernel_name(int id) {
       "k_cost", "k_lin_landmarks", "k_lin_poses", "k_pose_finalize", "k_dense_init",
       "k_schur_lds", "k_schur_partial", "k_schur_final", "k_scatter",
       "k_chol_diag", "k_chol_trsm", "k_chol_update", "k_chol_back", "k_chol_level", "k_chol_diag_trsm", "k_chol_tail", "k_backsub_update",
-      "k_pose_update", "k_scalars", "k_control", "k_damp_invert", "k_schur_grp", "k_lin_grp"};
+      "k_pose_update", "k_scalars", "k_control", "k_damp_invert", "k_schur_grp", "k_lin_grp", "k_backsub_lin"};
   return (id >= 0 && id < ba::K_COUNT) ? names[id] : "";
 }
 

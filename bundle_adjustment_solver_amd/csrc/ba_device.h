@@ -117,6 +117,7 @@ struct DevProblem {
   int2 *grp_pat;
   double *Apart2;            // n_apart2 * 27 pose-side partial sums of the group pieces
   double *lin_dump;          // kLinDump doubles: target of k_lin_grp's lanes with nothing to store
+  int *bl_flag, *pose_flag;  // k_backsub_lin: "piece back-substituted" (n_lin_desc) / "poses updated" (kPoseGrid) flags
   int32_t *pose_gpart_ptr, *pose_gpart;  // rows of Apart2 per pose
   int lin_chunk0;            // k_lin_landmarks starts at this chunk (the chunks before are k_lin_grp's)
   int n_lin_cost;            // entries of lin_cost_part: n_bchunk + k_lin_grp pieces
@@ -204,7 +205,7 @@ enum KernelId {
   K_COST = 0, K_LIN_LANDMARKS, K_LIN_POSES, K_POSE_FINALIZE, K_DENSE_INIT,
   K_SCHUR_LDS, K_SCHUR_PARTIAL, K_SCHUR_FINAL, K_SCATTER,
   K_CHOL_DIAG, K_CHOL_TRSM, K_CHOL_UPDATE, K_CHOL_BACK, K_CHOL_LEVEL, K_CHOL_DIAG_TRSM, K_CHOL_TAIL, K_BACKSUB_UPDATE,
-  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_DAMP_INVERT, K_SCHUR_GRP, K_LIN_GRP, K_COUNT
+  K_POSE_UPDATE, K_SCALARS, K_CONTROL, K_DAMP_INVERT, K_SCHUR_GRP, K_LIN_GRP, K_BACKSUB_LIN, K_COUNT
 };
 struct KernelTimer {
   bool on = false;
@@ -249,6 +250,8 @@ void launch_schur(const DevProblem &d, bool direct, bool with_init, hipStream_t 
 void launch_schur_accumulate(const DevProblem &d, hipStream_t s);
 void launch_schur_final(const DevProblem &d, bool direct, hipStream_t s);
 void launch_backsub_update(const DevProblem &d, hipStream_t s, bool zero_tiles = false);
+bool can_fuse_backsub_lin(const DevProblem &d);
+void launch_backsub_lin(const DevProblem &d, hipStream_t s, bool zero_tiles, int gen, int *bad);
 void launch_scatter(const DevProblem &d, hipStream_t s);
 // cost_src: 0 = the k_cost partials only (stage API), 1 = the k_lin_landmarks
 // partials (+ the k_cost partials of fixed-landmark observations, if any)

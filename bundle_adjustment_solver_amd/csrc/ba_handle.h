@@ -98,6 +98,7 @@ struct ba_handle {
   bool ev_ok = false;
   double stage_ms[ST_N] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool lm_begun = false;
+  int bl_gen = 0;            // generation number of the k_backsub_lin launches (flags are never reset)
   ba::KernelTimer kt;        // per-kernel event timing (diagnostic mode)
   ba::DenseSchedule sched;   // level schedule of the reduced-system Cholesky
   ba::DenseDev ddev;

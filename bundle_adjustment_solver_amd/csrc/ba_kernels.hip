@@ -703,31 +703,34 @@ __device__ long long g_lg_dbg[64];
 // pose in this landmark, found from a ballot of the step's valid lanes; when a pose has
 // no valid slot at all its static last slot stores the (zero-K) record, so that the W
 // image never keeps a previous step's entry.
-template <bool LDSCAM, bool MASKED>
-__global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, int piece0) {
+// FUSED (k_backsub_lin: the piece's landmarks were back-substituted and the poses updated
+// by workgroups of the SAME launch): the trial buffers are the other ones of ctrl->cur /
+// lcur, the workgroup waits for the pose workgroups' counter and for its piece's flag
+// (bounded polls) and reads poses and points with sc1 loads.
+// per wave: step transposition [64][9] + W image of the step; at the end [14][64]
+constexpr int kLgArea = 64 * 9 + 7 * 10 * 12;
+template <bool LDSCAM, bool MASKED, bool FUSED>
+__device__ __forceinline__ void lin_grp_body(const DevProblem &d, const int sel, const int bid, double *red,
+                                             double *cams_s, double *smc, int *slot_b, int *slot_e,
+                                             const int *bl_flag = nullptr, const int *pose_done = nullptr,
+                                             int gen = 0, int *bad = nullptr) {
 #ifdef BA_LG_DBG
   __shared__ long long lg_s[64];
   const bool lg_on = blockIdx.x == 300 && threadIdx.x == 0;
   int lg_n = 0;
 #endif
   LG_STAMP()
-  // per wave: step transposition [64][9] + W image of the step; at the end [14][64]
-  constexpr int kLgArea = 64 * 9 + 7 * 10 * 12;
-  __shared__ __attribute__((aligned(16))) double red[4 * kLgArea];
-  __shared__ double cams_s[kCamLds * 16];
-  __shared__ double smc[4];
-  __shared__ int slot_b[kGrpMaxPoses], slot_e[kGrpMaxPoses];  // pattern slots of pose jj of the group
-  const int bid = piece0 + blockIdx.x;
   const DevProblem::LinDesc *gp = d.lin_desc + bid;
   const int64_t p0 = gp->p0, o0 = gp->o0;
   const int l0 = gp->l0, nl = gp->nl, dd = gp->d, no = gp->no, pat0 = gp->pat0;
   const int apart0 = gp->apart0, cost_idx = gp->cost_idx;
   const int done = d.ctrl->done;
-  const int buf = sel ? d.ctrl->tcur : d.ctrl->cur;
-  const int lb = sel ? d.ctrl->tlcur : d.ctrl->lcur;
+  const int buf = FUSED ? (d.ctrl->cur ^ 1) : (sel ? d.ctrl->tcur : d.ctrl->cur);
+  const int lb = FUSED ? (d.ctrl->lcur ^ 1) : (sel ? d.ctrl->tlcur : d.ctrl->lcur);
   const double huber = d.ctrl->huber;
   if (LDSCAM) stage_cams(d, cams_s);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: everything derived from it leaves the vector registers)
   // landmarks per wave step; at most 7, so that the 9 nlw (landmark, value) sums of a
   // step are ONE lane each
   const int nlw = 64 / no < 7 ? 64 / no : 7;
@@ -747,11 +750,34 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, in
     }
   }
   const double *__restrict__ pts = d.pts[buf];
+#define LING_LDX(p_) (*(p_))
+  if (FUSED) {
+    if (tid <= kPoseGrid) {  // lanes 0..kPoseGrid-1: the pose workgroups' flags; lane kPoseGrid: the piece's flag
+      const int *fl = tid < kPoseGrid ? pose_done + tid : bl_flag + bid;
+      int spins = 0;
+      while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 22)) {  // ~ a second: give up, flag the iteration as failed
+          if (bad) atomicAdd(bad, ::ba::kFlowTimeout);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    // the piece's points (<= 672 landmarks): ONE sc1 read into the LDS behind the wave areas,
+    // the steps then take them from there (sc1 loads inside the step loop — past the L2,
+    // two steps of prefetch distance — made the role 2.4 times slower)
+    double *Xs = red + 4 * kLgArea;
+    for (int e = tid; e < nl * 3; e += kBlock)
+      Xs[e] = __hip_atomic_load(&pts[(size_t)l0 * 3 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pts = Xs - (size_t)l0 * 3;  // (the barrier below also covers Xs)
+  }
   double T[12], cam[16];
   {
     const double *Tp = d.poses[buf] + (size_t)pat.x * 12;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) T[k] = Tp[k];
+    for (int k = 0; k < 12; ++k)
+      T[k] = FUSED ? __hip_atomic_load(&Tp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Tp[k];
   }
   __syncthreads();  // cams_s, slot_b
   load_cam<LDSCAM>(d, cams_s, cam_id, cam);
@@ -786,9 +812,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, in
     const int ilc = clampi(il_of(u));
     uvq[u] = d.obs_uv[o0 + (int64_t)ilc * no + oo];
     const double *Xp = pts + (size_t)(l0 + ilc) * 3;
-    Xq[u][0] = Xp[0];
-    Xq[u][1] = Xp[1];
-    Xq[u][2] = Xp[2];
+    Xq[u][0] = LING_LDX(&Xp[0]);
+    Xq[u][1] = LING_LDX(&Xp[1]);
+    Xq[u][2] = LING_LDX(&Xp[2]);
   }
   // this lane's (landmark, value) sum of a wave step and where it goes
   const int sum_li = lane / 9, sum_v = lane - sum_li * 9;
@@ -848,9 +874,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, in
       const int ilc_ = clampi(il_of(st + 2));                                       \
       uvq[NXT2] = d.obs_uv[o0 + (int64_t)ilc_ * no + oo];                           \
       const double *Xp_ = pts + (size_t)(l0 + ilc_) * 3;                            \
-      Xq[NXT2][0] = Xp_[0];                                                         \
-      Xq[NXT2][1] = Xp_[1];                                                         \
-      Xq[NXT2][2] = Xp_[2];                                                         \
+      Xq[NXT2][0] = LING_LDX(&Xp_[0]);                                              \
+      Xq[NXT2][1] = LING_LDX(&Xp_[1]);                                              \
+      Xq[NXT2][2] = LING_LDX(&Xp_[2]);                                              \
     }                                                                               \
     const int il0_ = (st * 4 + wv) * nlw;                                           \
     const int il_ = il0_ + ilw;                                                     \
@@ -938,6 +964,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, in
   LING_FLUSH_ISSUE()
   LING_FLUSH_FINISH()
 #undef LING_STEP
+#undef LING_LDX
 #undef LING_FLUSH_ISSUE
 #undef LING_FLUSH_FINISH
   LG_STAMP()
@@ -969,6 +996,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, in
 #ifdef BA_LG_DBG
   if (lg_on) { for (int q = 0; q < 64; ++q) g_lg_dbg[q] = q < lg_n ? lg_s[q] : 0; }
 #endif
+}
+
+template <bool LDSCAM, bool MASKED>
+__global__ __launch_bounds__(kBlock, 2) void k_lin_grp(DevProblem d, int sel, int piece0) {
+  __shared__ __attribute__((aligned(16))) double red[4 * kLgArea];
+  __shared__ double cams_s[kCamLds * 16];
+  __shared__ double smc[4];
+  __shared__ int slot_b[kGrpMaxPoses], slot_e[kGrpMaxPoses];  // pattern slots of pose jj of the group
+  lin_grp_body<LDSCAM, MASKED, false>(d, sel, piece0 + blockIdx.x, red, cams_s, smc, slot_b, slot_e);
 }
 
 // Damping and landmark inverse (reference :846-856): Cinv_i = (C_i with its
@@ -2037,6 +2073,19 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
 // partial sums to pose_part[2 + 2b ..]; k_scalars adds them in block order.
 // Runs as the first kPoseGrid workgroups of the k_backsub_update launch (it needs
 // x only, like the back-substitution): no launch, no stream fork of its own.
+// Hand-offs between workgroups of ONE launch (k_backsub_lin): sc1 stores reach memory past the
+// XCD's L2, sc1 loads miss it — no fences (an agent-scope release / acquire writes back /
+// invalidates the whole L2 of the XCD: 2 000 of them per launch made it 3 times slower).
+template <bool SC1>
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+  if (SC1)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+// (SC1 — k_backsub_lin: the new poses are read by workgroups of the same launch on other XCDs,
+//  whose L2 is a different one: they leave with sc1 stores)
+template <bool SC1 = false>
 __device__ __forceinline__ void pose_update_body(const DevProblem &d, const int bid, double *sm) {
   const int cur = d.ctrl->cur;
   const int lbp = d.ctrl->lcur;
@@ -2091,11 +2140,9 @@ __device__ __forceinline__ void pose_update_body(const DevProblem &d, const int 
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        To[r * 3 + c] = dR[r * 3 + 0] * T[0 * 3 + c] +
-                        dR[r * 3 + 1] * T[1 * 3 + c] +
-                        dR[r * 3 + 2] * T[2 * 3 + c];
-      To[9 + r] = dR[r * 3 + 0] * T[9] + dR[r * 3 + 1] * T[10] +
-                  dR[r * 3 + 2] * T[11] + dt[r];
+        st_sc1<SC1>(&To[r * 3 + c], dR[r * 3 + 0] * T[0 * 3 + c] + dR[r * 3 + 1] * T[1 * 3 + c] +
+                                        dR[r * 3 + 2] * T[2 * 3 + c]);
+      st_sc1<SC1>(&To[9 + r], dR[r * 3 + 0] * T[9] + dR[r * 3 + 1] * T[10] + dR[r * 3 + 2] * T[11] + dt[r]);
     }
     const double *aj = d.a[lbp] + (size_t)j * 6;
     const double *Aj = d.A[lbp] + (size_t)j * 36;
@@ -2369,8 +2416,9 @@ __device__ __forceinline__ void backsub_chunk_body(const DevProblem &d, const in
 // redistributed through the wave's LDS image.  u = B_ji^T x_j per lane; one lane per
 // landmark adds its d vectors in pair order, inverts the damped C_i and updates the
 // point (reference :846-856, :907-925, :443-452).
+template <bool FUSED = false>
 __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int piece, const int part, double *lds,
-                                                 double *sm) {
+                                                 double *sm, int *bl_flag = nullptr, int gen = 0) {
   const DevProblem::LinDesc *gp = d.lin_desc + piece;
   const int64_t p0 = gp->p0;
   const int l0 = gp->l0, nl = gp->nl, dd = gp->d;
@@ -2570,6 +2618,18 @@ __device__ __forceinline__ void backsub_grp_body(const DevProblem &d, const int 
     d.lm_part[2 * part + 0] = est_acc;
     d.lm_part[2 * part + 1] = nrm_acc;
   }
+  if (FUSED) {
+    // k_backsub_lin: the piece's trial points go out ONCE MORE with sc1 stores (past this XCD's
+    // L2, for the linearisation workgroups on the other XCDs), then its flag is raised.  (sc1
+    // on the step loop's own stores would also hit the lanes that write to the dump word:
+    // thousands of write-throughs to one address, the role 4 times slower.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int e = tid; e < nl * 3; e += kBlock) st_sc1<true>(&Xt[(size_t)l0 * 3 + e], Xt[(size_t)l0 * 3 + e]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&bl_flag[piece], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Workgroup roles (by blockIdx, wave-uniform): [0, kPoseGrid) the pose update (see
@@ -2604,6 +2664,84 @@ __global__ __launch_bounds__(kBlock, GROUPS ? 2 : 4) void k_backsub_update(DevPr
   else
     backsub_chunk_body(d, part - d.n_bs_grp, part, lds, sm, recs);
 }
+// ---- back-substitution + update AND the trial-point linearisation in ONE launch ----
+// (problems whose free landmarks are all in covisibility groups, single GPU; OPT-IN,
+// BA_FUSE_BL=1.)  The idea: the two kernels look complementary — k_backsub_update is bound by
+// HBM (0.70 of the peak), k_lin_grp by the fp64 VALU (its memory side at 0.44) — and the
+// linearisation of a group piece needs only the poses and the points of ITS landmarks, so
+// run beside each other on the same CUs the pieces of one might fill the other's idle pipe.
+// MEASURED: they do not (see enqueue_iteration): interleaving is slower the finer it is;
+// with the roles one after the other the launch equals the two kernels and saves one
+// launch gap.  Roles from the block index:
+//   [0, kPoseGrid)   pose update; each raises pose_flag[b] = gen when its poses are out;
+//   then 2 P blocks: the first K are back-substitution pieces 0..K-1, then linearisation
+//                    piece m and back-substitution piece K + m alternate, the last K are
+//                    linearisation pieces (K = kBlLead: by the time piece m's linearisation
+//                    is dispatched its back-substitution, 2 K - 1 blocks earlier, is over);
+//   then             the reset of the factor tiles (k_dense_init role), as in k_backsub_update.
+// A linearisation workgroup waits for the pose flags and for its piece's flag — raised by
+// a block with a smaller index, i.e. one dispatched earlier; bounded polls — and reads poses and
+// points with sc1 loads (lin_grp_body<FUSED>); the producers store them with sc1 stores and
+// drain (s_waitcnt vmcnt(0)) before they raise their flag: no fences (see st_sc1).  Same arithmetic as the two launches
+// (BA_FUSE_BL=0), bit for bit.
+constexpr int kBlLead = 1 << 24;  // (default: no interleaving — the measured optimum, see enqueue_iteration)
+// (MASKED: the launch holds pieces of superset groups; their variant of the linearisation
+//  then takes every piece — for a piece without padded slots it performs the plain
+//  variant's arithmetic, the last writer found from the ballot is the static one)
+template <bool LDSCAM, bool MASKED>
+__global__ __launch_bounds__(kBlock, 2) void k_backsub_lin(DevProblem d, int gen, int *bad, int lead) {
+  __shared__ __attribute__((aligned(16))) double lds[kBsLds];
+  static_assert(kBsLds >= 4 * kLgArea + kLinGrpSteps * 4 * 7 * 3, "the linearisation role's LDS areas and its piece's points fit");
+  __shared__ double cams_s[kCamLds * 16];
+  __shared__ double sm[8];
+  __shared__ int slot_b[kGrpMaxPoses], slot_e[kGrpMaxPoses];
+  if (blockIdx.x < kPoseGrid) {
+    if (d.ctrl->done) return;
+    pose_update_body<true>(d, blockIdx.x, sm);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&d.pose_flag[blockIdx.x], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int P = d.n_bs_grp;
+  const int K = P < lead ? P : lead;
+  const int q = blockIdx.x - kPoseGrid;
+  // the alternating region in runs of eight: workgroups go to the eight XCDs round-robin, a
+  // strict alternation would put every linearisation piece on an even XCD and every back-
+  // substitution piece on an odd one
+  const int Q = P - K, G = (Q + 7) >> 3;
+  const int n_roles = 2 * K + 16 * G;
+  if (q >= n_roles) {  // role: reset of the factor tiles for the NEXT reduced system (k_dense_init)
+    if (d.ctrl->done) return;
+    const int z = q - n_roles;
+    const int I = d.zt_I[z], J = d.zt_J[z], nb = d.nb;
+    for (int e = threadIdx.x; e < nb * nb; e += kBlock) {
+      const int c = J * nb + e / nb, r = I * nb + e % nb;
+      d.L[(size_t)c * d.ld + r] = (r == c && d.col_x[c] < 0) ? 1.0 : 0.0;
+    }
+    return;
+  }
+  int piece;
+  bool lin;
+  if (q < K) {
+    piece = q;
+    lin = false;
+  } else if (q < K + 16 * G) {
+    const int r = q - K, g = r >> 4, w = r & 15;
+    lin = w < 8;
+    const int idx = 8 * g + (w & 7);
+    if (idx >= Q) return;  // (padding of the last run)
+    piece = lin ? idx : K + idx;
+  } else {
+    piece = Q + (q - (K + 16 * G));
+    lin = true;
+  }
+  if (!lin) {
+    backsub_grp_body<true>(d, piece, piece, lds, sm, d.bl_flag, gen);
+  } else
+    lin_grp_body<LDSCAM, MASKED, true>(d, 1, piece, lds, cams_s, sm, slot_b, slot_e, d.bl_flag, d.pose_flag, gen, bad);
+}
+
 #ifdef BA_BS_DBG
 extern "C" int ba_debug_read_bs(long long *out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_dbg), sizeof(long long) * 96);
@@ -2920,6 +3058,30 @@ void launch_backsub_update(const DevProblem &d, hipStream_t s, bool zero_tiles) 
     BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update<true>, grid, dim3(kBlock), s, d);
   else
     BA_LAUNCH(K_BACKSUB_UPDATE, k_backsub_update<false>, grid, dim3(kBlock), s, d);
+}
+
+// back-substitution + update + trial-point linearisation in one launch (see k_backsub_lin);
+// false: the problem does not qualify (chunk pieces beside the groups)
+bool can_fuse_backsub_lin(const DevProblem &d) {
+  return d.n_bs_grp > 0 && d.n_lm_part == d.n_bs_grp && d.n_lin_desc == d.n_bs_grp && d.n_bchunk == d.lin_chunk0 &&
+         d.bl_flag && d.pose_flag;
+}
+void launch_backsub_lin(const DevProblem &d, hipStream_t s, bool zero_tiles, int gen, int *bad) {
+  const bool masked = d.n_lin_desc > d.n_lin_plain;
+  static const int lead = getenv("BA_BL_LEAD") ? std::max(1, atoi(getenv("BA_BL_LEAD"))) : kBlLead;  // (tuning knob)
+  const int P = d.n_bs_grp, K = std::min(P, lead), G = (P - K + 7) / 8;
+  const dim3 grid(kPoseGrid + 2 * K + 16 * G + (zero_tiles ? d.n_zt : 0));
+  if (d.n_cam <= kCamLds) {
+    if (masked)
+      BA_LAUNCH(K_BACKSUB_LIN, (k_backsub_lin<true, true>), grid, dim3(kBlock), s, d, gen, bad, lead);
+    else
+      BA_LAUNCH(K_BACKSUB_LIN, (k_backsub_lin<true, false>), grid, dim3(kBlock), s, d, gen, bad, lead);
+  } else {
+    if (masked)
+      BA_LAUNCH(K_BACKSUB_LIN, (k_backsub_lin<false, true>), grid, dim3(kBlock), s, d, gen, bad, lead);
+    else
+      BA_LAUNCH(K_BACKSUB_LIN, (k_backsub_lin<false, false>), grid, dim3(kBlock), s, d, gen, bad, lead);
+  }
 }
 
 void launch_scalars(const DevProblem &d, int cost_src, hipStream_t s) {

@@ -1,5 +1,6 @@
 """Developer aid: where ba_finalize spends its time (BA_PLAN_TIMES laps) at a bench
-configuration, for several planner thread counts.  python tools/finalize_probe.py [C4] [threads ...]"""
+configuration.  python tools/finalize_probe.py [C4 | C4@12 (scale)] [passes ...]
+(BA_PLAN_THREADS is read once per process: set it in the environment.)"""
 import os
 import sys
 import time
@@ -9,9 +10,10 @@ os.environ["BA_PLAN_TIMES"] = "1"
 from bundle_adjustment_solver_amd import scenes  # noqa: E402
 from bundle_adjustment_solver_amd.solver import BaProblem  # noqa: E402
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"
-threads = sys.argv[2:] or ["16", "8", "1"]
-pr = scenes.scaled_problem(scenes.config_scene(cfg))
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"   # "C4" or "C4@12" (scale)
+threads = sys.argv[2:] or ["16"]
+scale = float(cfg.split("@")[1]) if "@" in cfg else 1.0
+pr = scenes.scaled_problem(scenes.config_scene(cfg.split("@")[0], scale))
 for rep, nt in enumerate(["16"] + threads):  # the first pass warms the allocator / page cache
     os.environ["BA_PLAN_THREADS"] = nt
     p = BaProblem(0)
