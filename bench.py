@@ -61,7 +61,7 @@ def algorithmic_bytes(O, P, M, N):
                 total=build + schur + solve + control)
 
 
-PMC_SUMMARY = {"C4": "profiles/r03_c4_pmc_fetch_write_v1.txt"}
+PMC_SUMMARY = {"C4": "profiles/r03_c4_pmc_fetch_write_v2.txt"}
 
 
 def pmc_traffic(kernel, config):

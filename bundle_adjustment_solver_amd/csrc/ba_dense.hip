@@ -548,7 +548,13 @@ void dense_factor_solve(double *L, int npad, int ld, double *Ldiag, double *x,
                    (dd.n_dag_items <= DenseDev::kDagMaxItems || dd.force_dag) && !dd.force_look2 &&
                    dd.fwd_flags && dd.fwd_cnt && dd.dag_dflags && dd.dag_tcnt && n_back > 0;
   // ... and beyond that item count: lookahead inside one launch per level (BA_DENSE_LOOK2=0: off)
-  const bool look2 = flow && split && !look && !dag && dd.want_look2 && dd.dag_dflags && dd.look_need &&
+  // (its waiting roles take their place from the block index: all of them — first targets, tiles
+  //  and TRSM items of a level — must be resident at once, whatever the dispatch order)
+  bool look2_fits = true;
+  for (int l = 0; l + 1 < sc.nlev - tail_levels && look2_fits; ++l)
+    look2_fits = (int)sc.tgt_first.size() > l &&
+                 sc.tgt_first[l] + (sc.lev_ptr[l + 2] - sc.lev_ptr[l + 1]) + (sc.item_ptr[l + 2] - sc.item_ptr[l + 1]) <= kFlowResident;
+  const bool look2 = flow && split && !look && !dag && dd.want_look2 && look2_fits && dd.dag_dflags && dd.look_need &&
                      dd.fwd_cnt &&
                      sc.nlev - tail_levels >= 3 &&
                      (int)sc.tgt_first.size() >= sc.nlev;
