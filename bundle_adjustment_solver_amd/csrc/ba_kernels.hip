@@ -2073,6 +2073,12 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevProblem d) {
 // partial sums to pose_part[2 + 2b ..]; k_scalars adds them in block order.
 // Runs as the first kPoseGrid workgroups of the k_backsub_update launch (it needs
 // x only, like the back-substitution): no launch, no stream fork of its own.
+// (as in ba_dense_tile.inc: the in-launch hand-offs of this file — k_backsub_lin — rely on gfx9-
+//  family behaviour: agent-scope relaxed atomics compile to sc1 accesses, s_waitcnt vmcnt(0)
+//  also drains the wave's stores)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "ba_kernels.hip relies on gfx9-family cache behaviour (sc1 hand-offs, LDS-only barriers): build for gfx950"
+#endif
 // Hand-offs between workgroups of ONE launch (k_backsub_lin): sc1 stores reach memory past the
 // XCD's L2, sc1 loads miss it — no fences (an agent-scope release / acquire writes back /
 // invalidates the whole L2 of the XCD: 2 000 of them per launch made it 3 times slower).

@@ -51,9 +51,11 @@ int plan_threads() {
   }();
   return n;
 }
+// (grain: indices a thread should at least get — 4096 for per-landmark loops; loops over
+//  runs / buckets of hundreds of landmarks pass a small one)
 template <class F>
-void parallel_for(int64_t n, const F &fn) {
-  const int nt = (int)std::min<int64_t>(plan_threads(), std::max<int64_t>(1, n / 4096));
+void parallel_for(int64_t n, const F &fn, int64_t grain = 4096) {
+  const int nt = (int)std::min<int64_t>(plan_threads(), std::max<int64_t>(1, n / grain));
   if (nt <= 1) {
     fn((int64_t)0, n);
     return;
@@ -424,7 +426,7 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           for (int64_t r = r0; r < r1; ++r)  // (regular scenes: one pattern per run, nothing to sort)
             if (!std::is_sorted(cand.begin() + run0[r], cand.begin() + run0[r + 1], less_sig))
               std::stable_sort(cand.begin() + run0[r], cand.begin() + run0[r + 1], less_sig);
-        });
+        }, 8);
       }
     }
     clk.lap("  groups: pattern sort");
@@ -487,7 +489,9 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
       }
       return n;
     };
-    auto exact_runs = [&](size_t lo, size_t hi) {
+    // (the group builders append to `out`; the caller numbers the groups and files their
+    //  members in group_of afterwards: buckets are processed on host threads)
+    auto exact_runs = [&](size_t lo, size_t hi, std::vector<GroupBuild> &out) {
       size_t a = lo;
       while (a < hi) {
         size_t b = a + 1;
@@ -498,17 +502,23 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
           gb.d = dop[cand[a]];
           gb.first_pose = first_pose(cand[a]);
           gb.last_pose = last_pose(cand[a]);
-          for (size_t t = a; t < b; ++t) {
-            gb.members.push_back(cand[t]);
-            group_of[cand[t]] = (int32_t)groups.size();
-          }
-          groups.push_back(std::move(gb));
+          for (size_t t = a; t < b; ++t) gb.members.push_back(cand[t]);
+          out.push_back(std::move(gb));
         }
         a = b;
       }
     };
+    auto adopt = [&](std::vector<GroupBuild> &from) {
+      for (GroupBuild &gb : from) {
+        for (int32_t i : gb.members) group_of[i] = (int32_t)groups.size();
+        groups.push_back(std::move(gb));
+      }
+      from.clear();
+    };
     if (!superset) {
-      exact_runs(0, cand.size());
+      std::vector<GroupBuild> out;
+      exact_runs(0, cand.size(), out);
+      adopt(out);
     } else {
       // buckets of equal (first pose, last pose); inside a bucket the pattern order stays
       // (stable, by two counting passes — last pose, then first pose)
@@ -524,52 +534,56 @@ std::string build_plan(const PlanInput &in, Plan &pl) {
         pass(span_lo, tmp, cand);
       }
       clk.lap("  groups: span sort");
-      size_t a = 0;
-      std::vector<uint64_t> uni;
-      while (a < cand.size()) {
-        size_t b = a + 1;
-        while (b < cand.size() && first_pose(cand[b]) == first_pose(cand[a]) && last_pose(cand[b]) == last_pose(cand[a]))
-          ++b;
-        if (same_sig(cand[a], cand[b - 1])) {  // (sorted by pattern: first == last => all equal)
-          exact_runs(a, b);
-          a = b;
-          continue;
-        }
-        // union of the duplicate-free members' patterns
-        uni.clear();
-        int64_t slots = 0;
-        int n_el = 0;
-        for (size_t t = a; t < b; ++t) {
-          const int i = cand[t];
-          if (has_dup(i)) continue;
-          uni.insert(uni.end(), pat.begin() + kp[i], pat.begin() + kp[i + 1]);
-          slots += deg(i);
-          ++n_el;
-        }
-        std::sort(uni.begin(), uni.end());
-        uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-        const int du = dopt_of(uni);
-        if (n_el >= kGrpMinLandmarks && (int)uni.size() <= kGrpMaxObs && du <= kGrpMaxPoses &&
-            (double)slots >= 0.55 * (double)n_el * (double)uni.size()) {
-          GroupBuild gb;
-          gb.upat = uni;
-          gb.d = du;
-          gb.first_pose = first_pose(cand[a]);
-          gb.last_pose = last_pose(cand[a]);
+      std::vector<size_t> bkt(1, 0);  // bucket boundaries
+      for (size_t t = 1; t < cand.size(); ++t)
+        if (first_pose(cand[t]) != first_pose(cand[t - 1]) || last_pose(cand[t]) != last_pose(cand[t - 1])) bkt.push_back(t);
+      bkt.push_back(cand.size());
+      const size_t nbkt = cand.empty() ? 0 : bkt.size() - 1;
+      std::vector<std::vector<GroupBuild>> bout(nbkt);
+      parallel_for((int64_t)nbkt, [&](int64_t k0, int64_t k1) {
+        std::vector<uint64_t> uni;
+        for (int64_t k = k0; k < k1; ++k) {
+          const size_t a = bkt[k], b = bkt[k + 1];
+          std::vector<GroupBuild> &out = bout[k];
+          if (same_sig(cand[a], cand[b - 1])) {  // (sorted by pattern: first == last => all equal)
+            exact_runs(a, b, out);
+            continue;
+          }
+          // union of the duplicate-free members' patterns
+          uni.clear();
+          int64_t slots = 0;
+          int n_el = 0;
           for (size_t t = a; t < b; ++t) {
             const int i = cand[t];
             if (has_dup(i)) continue;
-            gb.members.push_back(i);
-            group_of[i] = (int32_t)groups.size();
-            if (deg(i) < (int)uni.size()) gb.masked = true;
+            uni.insert(uni.end(), pat.begin() + kp[i], pat.begin() + kp[i + 1]);
+            slots += deg(i);
+            ++n_el;
           }
-          groups.push_back(std::move(gb));
-          // (members with duplicate observations: exact runs among themselves)
-        } else {
-          exact_runs(a, b);
+          std::sort(uni.begin(), uni.end());
+          uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+          const int du = dopt_of(uni);
+          if (n_el >= kGrpMinLandmarks && (int)uni.size() <= kGrpMaxObs && du <= kGrpMaxPoses &&
+              (double)slots >= 0.55 * (double)n_el * (double)uni.size()) {
+            GroupBuild gb;
+            gb.upat = uni;
+            gb.d = du;
+            gb.first_pose = first_pose(cand[a]);
+            gb.last_pose = last_pose(cand[a]);
+            for (size_t t = a; t < b; ++t) {
+              const int i = cand[t];
+              if (has_dup(i)) continue;
+              gb.members.push_back(i);
+              if (deg(i) < (int)uni.size()) gb.masked = true;
+            }
+            out.push_back(std::move(gb));
+            // (members with duplicate observations: exact runs among themselves)
+          } else {
+            exact_runs(a, b, out);
+          }
         }
-        a = b;
-      }
+      }, 8);
+      for (size_t k = 0; k < nbkt; ++k) adopt(bout[k]);
       clk.lap("  groups: buckets");
       // leftovers join a group whose union contains their pattern
       std::vector<std::vector<int32_t>> by_first(in.n_pose + 1);
