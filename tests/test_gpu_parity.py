@@ -529,6 +529,16 @@ def test_random_structures(seed, built):
     _compare_solve(scenes.scaled_problem(sc), iters=3, tol_par=1e-5)
 
 
+def test_stereo_windows_beyond_the_slot_limit_of_the_groups(built):
+    """20 stereo views per landmark = 40 observations: more than the 32 pattern slots of a
+    covisibility group (one lane per slot in k_lin_grp), so nothing is grouped although the
+    20 poses would fit: pose-group classes / chunk kernels, against the oracle."""
+    sc = scenes.synthetic_ba_scene(44, 1800, 20, True, seed=71, pixel_sigma=0.2)
+    pr = scenes.scaled_problem(sc)
+    g, o = _compare_solve(pr, iters=5, tol_par=1e-5)
+    assert g.get_schur_info()["grouped_landmarks"] < 0.2 * g.M_global
+
+
 @pytest.mark.parametrize("window", [15, 16, 20])
 def test_wide_windows_around_the_slot_limit(window, built):
     """A landmark seen by d poses touches d(d+1)/2 blocks of S: d = 15 (120
