@@ -529,6 +529,25 @@ def test_random_structures(seed, built):
     _compare_solve(scenes.scaled_problem(sc), iters=3, tol_par=1e-5)
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_wide_window_scenes(seed, built):
+    """Randomised scenes on the round-3 paths: windows of 11..20 poses (mono) or 11..16
+    (stereo), 0-30 % of the observations dropped, some landmarks fixed, group sizes around
+    the 24-landmark threshold (so that wide groups, masked wide groups, pose-group classes and
+    the triple list all occur in one problem): reduced system, four LM iterations and the
+    final parameters against the oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    stereo = bool(rng.integers(0, 2))
+    window = int(rng.integers(11, 17 if stereo else 21))
+    n_pose = int(rng.integers(window + 8, 70))
+    n_pt = int(rng.integers(600, 4000))
+    sc = scenes.synthetic_ba_scene(n_pose, n_pt, window, stereo, seed=6000 + seed,
+                                   pixel_sigma=float(rng.choice([0.0, 0.3])),
+                                   dropout=float(rng.choice([0.0, 0.1, 0.3])))
+    sc["pt_fixed"][rng.uniform(size=sc["pt_fixed"].shape[0]) < 0.05] = True
+    _compare_solve(scenes.scaled_problem(sc), iters=4, tol_par=1e-5)
+
+
 def test_stereo_windows_beyond_the_slot_limit_of_the_groups(built):
     """20 stereo views per landmark = 40 observations: more than the 32 pattern slots of a
     covisibility group (one lane per slot in k_lin_grp), so nothing is grouped although the
