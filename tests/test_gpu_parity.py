@@ -371,7 +371,9 @@ def test_one_stream_iteration_and_dataflow_sweep_equal_their_fallbacks(built):
     the grid is resident, from tickets otherwise: BA_DENSE_TICKET=1 forces tickets);
     BA_FUSE_BL=1 (opt-in) runs back-substitution and trial-point linearisation as roles of
     ONE launch (k_backsub_lin: per-piece flags, sc1 hand-offs; BA_BL_LEAD=8 interleaves them
-    finely so that the linearisation workgroups really wait for their flags);
+    finely so that the linearisation workgroups really wait for their flags); BA_GRAPH=1 replays
+    the iteration as a captured hipGraph (per-level launches: the generation number of the
+    dataflow launches is a kernel argument);
     BA_FORCE_SIDE=1 (side stream with fork / join) and BA_DENSE_FLOW=0 (separate
     diag_trsm / update launches, one backward launch per level) are the paths every
     other problem takes; BA_DENSE_FWD_FLOW=1 is the opt-in form that runs ALL levels of
@@ -384,7 +386,7 @@ def test_one_stream_iteration_and_dataflow_sweep_equal_their_fallbacks(built):
     for env in ({}, {"BA_FORCE_SIDE": "1"}, {"BA_DENSE_FLOW": "0"}, {"BA_FORCE_SIDE": "1", "BA_DENSE_FLOW": "0"},
                 {"BA_DENSE_TICKET": "1"}, {"BA_FUSE_BL": "1"}, {"BA_FUSE_BL": "1", "BA_BL_LEAD": "8"},
                 {"BA_DENSE_FWD_FLOW": "1"},
-                {"BA_DENSE_FWD_FLOW": "1", "BA_DENSE_TICKET": "1"}):
+                {"BA_DENSE_FWD_FLOW": "1", "BA_DENSE_TICKET": "1"}, {"BA_GRAPH": "1"}):
         for k, v in env.items():
             os.environ[k] = v
         try:
