@@ -531,6 +531,74 @@ def test_random_structures(seed, built):
     _compare_solve(scenes.scaled_problem(sc), iters=3, tol_par=1e-5)
 
 
+@pytest.mark.parametrize("stereo", [False, True])
+def test_minimiser_matches_an_independent_least_squares_solver(stereo, built):
+    """INDEPENDENT (non-restatement) check of the full bundle-adjustment path: with the robust
+    weight off (Huber threshold far above every residual) the solver's fixed point is the
+    minimiser of the sum of squared reprojection errors.  scipy.optimize.least_squares
+    (trust-region reflective, finite-difference Jacobian of a plain numpy projection written
+    here, its own pose parametrisation) started from the same values must end in the same
+    minimum: squared-error sums equal to 1e-6 relative, poses and points to 1e-4 of the scene
+    scale (the LM loop with its thresholds off ends in an accept / reject cycle at its noise
+    floor: 5e-8 / 6e-5 on the mono scene, 1e-10 / 1e-6 on the stereo scene).
+    Neither the oracle nor any analytic Jacobian of this repository takes part."""
+    from scipy.optimize import least_squares
+    sc = scenes.synthetic_ba_scene(8, 70, 5, stereo, seed=91, pixel_sigma=0.5, pose_noise=0.01, point_noise=0.03)
+    pr = scenes.scaled_problem(sc)
+    intr, camT = pr["cam_intr"], pr["cam_T"]
+    T0, X0 = pr["pose_T"].copy(), pr["pt_X"].copy()
+    pf, xf = pr["pose_fixed"].astype(bool), pr["pt_fixed"].astype(bool)
+    oc, op, ox, uv = pr["obs_cam"], pr["obs_pose"], pr["obs_pt"], pr["obs_uv"]
+    free_p, free_x = np.flatnonzero(~pf), np.flatnonzero(~xf)
+
+    def rodrigues(w):
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if th < 1e-12:
+            return np.eye(3) + K
+        return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+    def unpack(z):
+        T, X = T0.copy(), X0.copy()
+        for a, j in enumerate(free_p):   # T_j = [exp(w) R0 | t0 + v]: any smooth chart has the same minimiser
+            w, v = z[6 * a:6 * a + 3], z[6 * a + 3:6 * a + 6]
+            T[j, :9] = (rodrigues(w) @ T0[j, :9].reshape(3, 3)).reshape(9)
+            T[j, 9:] = T0[j, 9:] + v
+        X[free_x] = X0[free_x] + z[6 * len(free_p):].reshape(-1, 3)
+        return T, X
+
+    def residuals(z):
+        T, X = unpack(z)
+        R = T[op, :9].reshape(-1, 3, 3)
+        Xj = np.einsum("kab,kb->ka", R, X[ox]) + T[op, 9:]
+        Rc = camT[oc, :9].reshape(-1, 3, 3)
+        Xc = np.einsum("kab,kb->ka", Rc, Xj) + camT[oc, 9:]
+        u = intr[oc, 0] * Xc[:, 0] / Xc[:, 2] + intr[oc, 2]
+        v = intr[oc, 1] * Xc[:, 1] / Xc[:, 2] + intr[oc, 3]
+        return np.concatenate([u - uv[:, 0], v - uv[:, 1]])
+
+    z0 = np.zeros(6 * len(free_p) + 3 * len(free_x))
+    ls = least_squares(residuals, z0, method="trf", jac="3-point", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=400)
+    T_ls, X_ls = unpack(ls.x)
+    g = make_gpu(pr)
+    g.solve(make_options(max_iter=80, thr_step=0, thr_cost=0, huber=1e9))
+    Tg, Xg = g.get_poses(), g.get_points()[0]
+    # squared-error sum at the solver's result, evaluated by the numpy projection above
+    def sse(T, X):
+        R = T[op, :9].reshape(-1, 3, 3)
+        Xj = np.einsum("kab,kb->ka", R, X[ox]) + T[op, 9:]
+        Xc = np.einsum("kab,kb->ka", camT[oc, :9].reshape(-1, 3, 3), Xj) + camT[oc, 9:]
+        u = intr[oc, 0] * Xc[:, 0] / Xc[:, 2] + intr[oc, 2]
+        v = intr[oc, 1] * Xc[:, 1] / Xc[:, 2] + intr[oc, 3]
+        return float(((u - uv[:, 0]) ** 2 + (v - uv[:, 1]) ** 2).sum())
+    s_gpu, s_ls, s_0 = sse(Tg, Xg), sse(T_ls, X_ls), sse(T0, X0)
+    assert s_ls < 0.5 * s_0 and s_gpu < 0.5 * s_0            # both moved well away from the start
+    assert abs(s_gpu - s_ls) <= 1e-6 * s_ls, (s_gpu, s_ls)
+    scale = np.abs(X0).max()
+    assert np.abs(Tg - T_ls).max() <= 1e-4 * scale, np.abs(Tg - T_ls).max()
+    assert np.abs(Xg - X_ls).max() <= 1e-4 * scale, np.abs(Xg - X_ls).max()
+
+
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_random_wide_window_scenes(seed, built):
     """Randomised scenes on the round-3 paths: windows of 11..20 poses (mono) or 11..16

@@ -413,3 +413,58 @@ def test_nan_cost_takes_the_skipped_branch_with_lambda_unchanged():
     for r in rows:
         assert r.iteration_status == 2 and r.damping_term == 100.0
         assert np.isnan(r.trial_cost) and np.isnan(r.rho)
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_oracle_minimiser_matches_an_independent_least_squares_solver(stereo, built):
+    """INDEPENDENT (non-restatement) pin of the whole bundle-adjustment path of the oracle:
+    with the robust weight off its fixed point is the minimiser of the sum of squared
+    reprojection errors; scipy.optimize.least_squares (trust-region reflective, finite-
+    difference Jacobian of the plain numpy projection below, its own pose chart) started from
+    the same values ends in the same minimum — squared-error sums to 1e-6 relative, poses and
+    points to 1e-4 of the scene scale (the LM loop with thresholds off cycles accept / reject
+    at its noise floor).  tests/test_gpu_parity.py holds the same check for the HIP path."""
+    from scipy.optimize import least_squares
+    sc = scenes.synthetic_ba_scene(8, 70, 5, stereo, seed=91, pixel_sigma=0.5, pose_noise=0.01, point_noise=0.03)
+    pr = scenes.scaled_problem(sc)
+    intr, camT = pr["cam_intr"], pr["cam_T"]
+    T0, X0 = pr["pose_T"].copy(), pr["pt_X"].copy()
+    free_p = np.flatnonzero(pr["pose_fixed"] == 0)
+    free_x = np.flatnonzero(pr["pt_fixed"] == 0)
+    oc, op, ox, uv = pr["obs_cam"], pr["obs_pose"], pr["obs_pt"], pr["obs_uv"]
+
+    def rodrigues(w):
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if th < 1e-12:
+            return np.eye(3) + K
+        return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+    def unpack(z):
+        T, X = T0.copy(), X0.copy()
+        for a, j in enumerate(free_p):
+            w, v = z[6 * a:6 * a + 3], z[6 * a + 3:6 * a + 6]
+            T[j, :9] = (rodrigues(w) @ T0[j, :9].reshape(3, 3)).reshape(9)
+            T[j, 9:] = T0[j, 9:] + v
+        X[free_x] = X0[free_x] + z[6 * len(free_p):].reshape(-1, 3)
+        return T, X
+
+    def res(T, X):
+        Xj = np.einsum("kab,kb->ka", T[op, :9].reshape(-1, 3, 3), X[ox]) + T[op, 9:]
+        Xc = np.einsum("kab,kb->ka", camT[oc, :9].reshape(-1, 3, 3), Xj) + camT[oc, 9:]
+        u = intr[oc, 0] * Xc[:, 0] / Xc[:, 2] + intr[oc, 2]
+        v = intr[oc, 1] * Xc[:, 1] / Xc[:, 2] + intr[oc, 3]
+        return np.concatenate([u - uv[:, 0], v - uv[:, 1]])
+
+    z0 = np.zeros(6 * len(free_p) + 3 * len(free_x))
+    ls = least_squares(lambda z: res(*unpack(z)), z0, method="trf", jac="3-point",
+                       xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=400)
+    T_ls, X_ls = unpack(ls.x)
+    o = O.Oracle(pr)
+    o.solve(O.make_options(max_iter=80, thr_step=0, thr_cost=0, huber=1e9))
+    To, Xo = o.get_poses(), o.get_points()
+    sse = lambda T, X: float((res(T, X) ** 2).sum())
+    assert sse(T_ls, X_ls) < 0.5 * sse(T0, X0)
+    assert abs(sse(To, Xo) - sse(T_ls, X_ls)) <= 1e-6 * sse(T_ls, X_ls)
+    scale = np.abs(X0).max()
+    assert np.abs(To - T_ls).max() <= 1e-4 * scale and np.abs(Xo - X_ls).max() <= 1e-4 * scale
